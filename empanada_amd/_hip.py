@@ -1,0 +1,300 @@
+"""ctypes binding of libemp_hip.so (the C ABI in include/emp_hip.h).
+
+The HIP library is the product; there is NO CPU fallback here.  If the shared library is
+missing (not built) or a kernel is asked to run without a GPU, this module raises.
+torch is used only to own device memory and to name the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libemp_hip.so')
+
+MAX_KS = 11
+MAX_CLASSES = 16
+MAX_CENTERS = 4096
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_L = _c.c_int64
+_F = _c.c_float
+_U32 = _c.c_uint32
+
+# name -> (restype, argtypes); mirrors include/emp_hip.h one to one
+SIGNATURES = {
+    'emp_version': (_I, []),
+    'emp_last_error': (_c.c_char_p, []),
+    'emp_device_count': (_I, []),
+    'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
+    'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
+    'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
+    'emp_find_centers': (_I, [_P, _I, _I, _I, _F, _I, _I, _P, _P, _P]),
+    'emp_group_pixels': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    'emp_fuse_work_elems': (_L, [_I, _I, _I]),
+    'emp_fuse_panoptic': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _U32, _L, _L, _L, _P, _P, _P, _P]),
+    'emp_runs_count': (_I, [_P, _I, _I, _I, _P, _P]),
+    'emp_scan_tmp_elems': (_L, [_L]),
+    'emp_exclusive_scan_i32': (_I, [_P, _L, _P, _P, _P]),
+    'emp_runs_extract': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'emp_runs_label_work_elems': (_L, [_L]),
+    'emp_runs_label': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _L, _U32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'emp_runs_overlap_next': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P, _L, _P, _P]),
+    'emp_rle_pair_intersections': (_I, [_P, _P, _P, _P, _L, _P, _P]),
+    'emp_sort_work_bytes': (_L, [_L]),
+    'emp_sort_u64_i32': (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
+    'emp_vote_work_bytes': (_L, [_L]),
+    'emp_vote_ranges': (_I, [_P, _P, _P, _L, _I, _I, _P, _L, _P, _P, _P]),
+    'emp_fill_runs_u32': (_I, [_P, _L, _P, _P, _P, _L, _P, _P]),
+    'emp_fill_runs_u8': (_I, [_P, _L, _P, _P, _L, _c.c_uint8, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libemp_hip.so (no GPU needed for this) and bind every symbol of the ABI."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(f"{LIB_PATH} not found: build it with `python -m empanada_amd.build` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the ABI and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HipError("empanada_amd needs an MI355X (HIP device) for this operation; no CPU fallback exists")
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return t.data_ptr()
+
+
+def as_u32(t):
+    """reinterpret / convert an integer cuda tensor as uint32 (torch has few native uint32 ops)."""
+    if t.dtype == torch.uint32:
+        return t
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)          # keeps the low 32 bits
+    return t.contiguous().view(torch.uint32)
+
+
+def np_to_dev_u32(a):
+    import numpy as np
+    a = np.ascontiguousarray(a).astype(np.uint32)
+    return torch.from_numpy(a.view(np.int32)).cuda().view(torch.uint32)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Call an int-returning ABI function; raise HipError with emp_last_error() on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise HipError(f"{name} failed ({rc}): {lib.emp_last_error().decode()}")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)
+
+
+# ----------------------------------------------------------------------------- thin typed wrappers
+def median_harden_stack(prob, ks, thr, want_prob=False):
+    """prob (D,C,H,W) fp32 cuda -> sem (D,H,W) u8 [, filtered prob (D,C,H,W)]."""
+    require_gpu()
+    D, C, H, W = prob.shape
+    prob = prob.contiguous()
+    sem = torch.empty((D, H, W), dtype=torch.uint8, device=prob.device)
+    outp = torch.empty_like(prob) if want_prob else None
+    call('emp_median_harden_stack', _ptr(prob), D, C, H * W, int(ks), float(thr), _ptr(sem), _ptr(outp), stream())
+    return (sem, outp) if want_prob else sem
+
+
+def median_step(slices, out=None):
+    """median over a list of ks same-shape fp32 cuda tensors (engines.py:59-66)."""
+    require_gpu()
+    ks = len(slices)
+    slices = [s.contiguous() for s in slices]
+    n = slices[0].numel()
+    if out is None:
+        out = torch.empty_like(slices[0])
+    arr = (_P * ks)(*[s.data_ptr() for s in slices])
+    call('emp_median_step', arr, ks, n, _ptr(out), stream())
+    return out
+
+
+def find_centers(hmp, thr, k, cap=1024):
+    """hmp (D,h,w) fp32 -> idx (D,cap) int32 raster-sorted, count (D) int32."""
+    require_gpu()
+    D, h, w = hmp.shape
+    hmp = hmp.contiguous()
+    idx = torch.empty((D, cap), dtype=torch.int32, device=hmp.device)
+    cnt = torch.empty((D,), dtype=torch.int32, device=hmp.device)
+    call('emp_find_centers', _ptr(hmp), D, h, w, float(thr), int(k), int(cap), _ptr(idx), _ptr(cnt), stream())
+    return idx, cnt
+
+
+def group_pixels(idx, cnt, offsets, step):
+    """offsets (D,2,h,w) fp32 -> ids (D,h,w) uint16."""
+    require_gpu()
+    D, _, h, w = offsets.shape
+    offsets = offsets.contiguous()
+    ids = torch.empty((D, h, w), dtype=torch.uint16, device=offsets.device)
+    call('emp_group_pixels', _ptr(idx), _ptr(cnt), idx.shape[1], _ptr(offsets), D, h, w, int(step), _ptr(ids),
+         stream())
+    return ids
+
+
+def fuse_panoptic(sem, ids, cap, n_classes, thing_list, label_divisor, stuff_area, void_label, up=1,
+                  out_dtype=torch.uint32):
+    """sem (D,H,W) u8, ids (D,H/up,W/up) u16 -> pan (D,H,W) uint32 or int64."""
+    require_gpu()
+    D, H, W = sem.shape
+    mask = 0
+    for t in thing_list:
+        mask |= 1 << int(t)
+    work = torch.empty((query('emp_fuse_work_elems', D, int(cap), int(n_classes)),), dtype=torch.int32,
+                       device=sem.device)
+    pan = torch.empty((D, H, W), dtype=out_dtype, device=sem.device)
+    p32 = _ptr(pan) if out_dtype == torch.uint32 else None
+    p64 = _ptr(pan) if out_dtype == torch.int64 else None
+    assert (p32 is None) != (p64 is None), "out_dtype must be torch.uint32 or torch.int64"
+    call('emp_fuse_panoptic', _ptr(sem.contiguous()), _ptr(ids.contiguous()), D, H, W, int(up), int(cap),
+         int(n_classes), mask, int(label_divisor), int(stuff_area), int(void_label), _ptr(work), p32, p64, stream())
+    return pan
+
+
+def exclusive_scan_i32(x):
+    require_gpu()
+    n = x.numel()
+    out = torch.empty((n + 1,), dtype=torch.int32, device=x.device)
+    tmp = torch.empty((query('emp_scan_tmp_elems', n),), dtype=torch.int32, device=x.device)
+    call('emp_exclusive_scan_i32', _ptr(x), n, _ptr(out), _ptr(tmp), stream())
+    return out
+
+
+class RunTable:
+    """Result of extract_runs(): SoA run table + components of a (D,H,W) uint32 label stack."""
+    __slots__ = ('D', 'H', 'W', 'n_runs', 'n_comp', 'row_offsets', 'r_start', 'r_len', 'r_val', 'r_comp',
+                 'c_slice', 'c_label', 'c_area', 'c_box', 'c_first')
+
+
+def extract_runs(pan, label_divisor, cc_classes):
+    """pan (D,H,W) uint32 cuda -> RunTable (device tensors; two small host syncs for the counts)."""
+    require_gpu()
+    D, H, W = pan.shape
+    pan = pan.contiguous()
+    dev = pan.device
+    rows = torch.empty((D * H,), dtype=torch.int32, device=dev)
+    call('emp_runs_count', _ptr(pan), D, H, W, _ptr(rows), stream())
+    offs = exclusive_scan_i32(rows)
+    n_runs = int(offs[-1].item())
+    t = RunTable()
+    t.D, t.H, t.W, t.n_runs, t.row_offsets = D, H, W, n_runs, offs
+    t.r_start = torch.empty((max(n_runs, 1),), dtype=torch.int32, device=dev)
+    t.r_len = torch.empty_like(t.r_start)
+    t.r_val = torch.empty((max(n_runs, 1),), dtype=torch.uint32, device=dev)
+    call('emp_runs_extract', _ptr(pan), D, H, W, _ptr(offs), _ptr(t.r_start), _ptr(t.r_len), _ptr(t.r_val), stream())
+    mask = 0
+    for c in cc_classes:
+        mask |= 1 << int(c)
+    work = torch.empty((query('emp_runs_label_work_elems', n_runs),), dtype=torch.int32, device=dev)
+    m = max(n_runs, 1)
+    t.r_comp = torch.empty((m,), dtype=torch.int32, device=dev)
+    t.c_slice = torch.empty((m,), dtype=torch.int32, device=dev)
+    t.c_label = torch.empty((m,), dtype=torch.int64, device=dev)
+    t.c_area = torch.empty((m,), dtype=torch.int64, device=dev)
+    t.c_box = torch.empty((m, 4), dtype=torch.int32, device=dev)
+    t.c_first = torch.empty((m,), dtype=torch.int32, device=dev)
+    ncomp = torch.zeros((1,), dtype=torch.int32, device=dev)
+    call('emp_runs_label', _ptr(t.r_start), _ptr(t.r_len), _ptr(t.r_val), _ptr(offs), n_runs, D, H, W,
+         int(label_divisor), mask, _ptr(work), _ptr(t.r_comp), _ptr(t.c_slice), _ptr(t.c_label), _ptr(t.c_area),
+         _ptr(t.c_box), _ptr(t.c_first), _ptr(ncomp), stream())
+    t.n_comp = int(ncomp.item())
+    for name in ('r_start', 'r_len', 'r_val', 'r_comp'):
+        setattr(t, name, getattr(t, name)[:n_runs])
+    for name in ('c_slice', 'c_label', 'c_area', 'c_box', 'c_first'):
+        setattr(t, name, getattr(t, name)[:t.n_comp])
+    return t
+
+
+def overlap_next(t, label_divisor):
+    """(comp_a, comp_b, overlap) int32 triplets between consecutive slices of a RunTable (device)."""
+    require_gpu()
+    dev = t.r_start.device
+    cap = max(4 * t.n_runs, 1024)
+    while True:
+        out = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+        n = torch.zeros((1,), dtype=torch.int32, device=dev)
+        call('emp_runs_overlap_next', _ptr(t.r_start), _ptr(t.r_len), _ptr(t.r_comp), _ptr(t.c_label),
+             _ptr(t.row_offsets), t.n_runs, t.D, t.H, t.W, int(label_divisor), _ptr(out), cap, _ptr(n), stream())
+        cnt = int(n.item())
+        if cnt <= cap:
+            return out[:cnt]
+        cap = cnt
+
+
+def sort_u64_i32(keys, vals, begin_bit=0, end_bit=64):
+    require_gpu()
+    n = keys.numel()
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    wb = query('emp_sort_work_bytes', n)
+    work = torch.empty((wb,), dtype=torch.uint8, device=keys.device)
+    call('emp_sort_u64_i32', _ptr(keys), _ptr(ko), _ptr(vals), _ptr(vo), n, begin_bit, end_bit, _ptr(work), wb, stream())
+    return ko, vo
+
+
+def vote_ranges(starts, ends, grp, n_groups, vote_thr):
+    """ranges (int64 cuda) tagged with int32 group ids -> (out_ranges (m,2) int64, out_off (n_groups+1) int32)."""
+    require_gpu()
+    n = starts.numel()
+    dev = starts.device
+    wb = query('emp_vote_work_bytes', n)
+    work = torch.empty((wb,), dtype=torch.uint8, device=dev)
+    out = torch.empty((max(n, 1), 2), dtype=torch.int64, device=dev)
+    off = torch.empty((n_groups + 1,), dtype=torch.int32, device=dev)
+    call('emp_vote_ranges', _ptr(starts.contiguous()), _ptr(ends.contiguous()), _ptr(grp.contiguous()), n,
+         int(n_groups), int(vote_thr), _ptr(work), wb, _ptr(out), _ptr(off), stream())
+    return out, off
+
+
+def rle_pair_intersections(starts, lens, inst_off, pairs):
+    require_gpu()
+    n_pairs = pairs.shape[0]
+    out = torch.empty((n_pairs,), dtype=torch.int64, device=starts.device)
+    call('emp_rle_pair_intersections', _ptr(starts), _ptr(lens), _ptr(inst_off), _ptr(pairs.contiguous()), n_pairs,
+         _ptr(out), stream())
+    return out
+
+
+def fill_runs_u32(vol, starts, lens, order, ids):
+    require_gpu()
+    call('emp_fill_runs_u32', _ptr(vol), vol.numel(), _ptr(starts), _ptr(lens), _ptr(order), starts.numel(),
+         _ptr(ids), stream())
+    return vol
+
+
+def fill_runs_u8(vol, starts, lens, value):
+    require_gpu()
+    call('emp_fill_runs_u8', _ptr(vol), vol.numel(), _ptr(starts), _ptr(lens), starts.numel(), int(value), stream())
+    return vol

@@ -1,0 +1,608 @@
+// Per-pixel kernels of the panoptic post-processing: recursive median + harden (P1/P2),
+// centre NMS (P3), nearest-centre grouping (P4), semantic/instance fusion (P5).
+// gfx950 only; wave = 64.  All HBM-bound except group_pixels at large K (VALU-bound).
+#include "emp_common.h"
+
+thread_local char emp_err_buf[512] = "";
+
+extern "C" int emp_version(void) { return 100; }
+extern "C" const char *emp_last_error(void) { return emp_err_buf; }
+extern "C" int emp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// median of KS registers (odd KS): partial bubble, m+1 passes leave the median at v[m].
+template <int KS>
+__device__ __forceinline__ float median_regs(const float (&in)[KS])
+{
+    float v[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) v[i] = in[i];
+    constexpr int M = KS / 2;
+#pragma unroll
+    for (int pass = 0; pass <= M; ++pass) {
+#pragma unroll
+        for (int i = 0; i < KS - 1 - pass; ++i) {
+            float lo = fminf(v[i], v[i + 1]);
+            float hi = fmaxf(v[i], v[i + 1]);
+            v[i] = lo;
+            v[i + 1] = hi;
+        }
+    }
+    return v[M];
+}
+
+// ------------------------------------------------------------------------------------------
+// P1+P2, C == 1: one thread per pixel walks the stack in z with the filter window in registers.
+// Loads of the next PF slices are issued before the current PF medians are computed so that
+// every lane keeps PF dword loads in flight (the recursion itself is serial in z).
+// Algorithmic traffic: 4 B read + 1 B write per voxel (+4 B if out_prob).
+template <int KS>
+__global__ __launch_bounds__(256) void median_harden_c1_kernel(const float *__restrict__ prob, int D,
+                                                               int64_t HW, float thr,
+                                                               uint8_t *__restrict__ out_sem,
+                                                               float *__restrict__ out_prob)
+{
+    constexpr int M = KS / 2;
+    constexpr int PF = 8;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < HW;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const float *src = prob + p;
+        float win[KS];
+        // slices 0..KS-2 enter the window; the first M of them pass through raw
+#pragma unroll
+        for (int i = 0; i < KS - 1; ++i) win[i] = src[(int64_t)i * HW];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            out_sem[(int64_t)i * HW + p] = win[i] >= thr ? 1 : 0;
+            if (out_prob) out_prob[(int64_t)i * HW + p] = win[i];
+        }
+        float cur[PF], nxt[PF];
+        const int s_end = D - M;  // filtered slices are [M, s_end)
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            int z = M + u + M;
+            cur[u] = (z < D) ? src[(int64_t)z * HW] : 0.f;
+        }
+        for (int s0 = M; s0 < s_end; s0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                int z = s0 + PF + u + M;
+                nxt[u] = (z < D) ? src[(int64_t)z * HW] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                int s = s0 + u;
+                if (s < s_end) {
+                    win[KS - 1] = cur[u];
+                    float med = median_regs<KS>(win);
+                    out_sem[(int64_t)s * HW + p] = med >= thr ? 1 : 0;
+                    if (out_prob) out_prob[(int64_t)s * HW + p] = med;
+                    // slide: the filtered value replaces the raw one (recursive filter)
+                    win[M] = med;
+#pragma unroll
+                    for (int i = 0; i < KS - 1; ++i) win[i] = win[i + 1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) cur[u] = nxt[u];
+        }
+        // tail: win[M .. KS-2] hold the raw slices D-M .. D-1
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            int s = D - M + i;
+            float v = win[M + i];
+            out_sem[(int64_t)s * HW + p] = v >= thr ? 1 : 0;
+            if (out_prob) out_prob[(int64_t)s * HW + p] = v;
+        }
+    }
+}
+
+// P1+P2, C > 1: same scan, one filter window per channel kept in LDS ([c][k][tid] -> conflict
+// free), argmax over the filtered channels (first maximum wins, like torch.argmax).
+template <int KS>
+__global__ __launch_bounds__(256) void median_harden_mc_kernel(const float *__restrict__ prob, int D,
+                                                               int C, int64_t HW,
+                                                               uint8_t *__restrict__ out_sem,
+                                                               float *__restrict__ out_prob)
+{
+    extern __shared__ float lds[];  // C * KS * blockDim.x
+    constexpr int M = KS / 2;
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;
+    for (int64_t p0 = (int64_t)blockIdx.x * nt; p0 < HW; p0 += (int64_t)gridDim.x * nt) {
+        int64_t p = p0 + tid;
+        bool live = p < HW;
+        if (live) {
+            for (int c = 0; c < C; ++c)
+                for (int i = 0; i < KS - 1; ++i)
+                    lds[(c * KS + i) * nt + tid] = prob[((int64_t)i * C + c) * HW + p];
+            for (int s = 0; s < D; ++s) {
+                bool filt = (s >= M) && (s < D - M);
+                float best = -INFINITY;
+                int arg = 0;
+                for (int c = 0; c < C; ++c) {
+                    float v;
+                    if (filt) {
+                        float w[KS];
+                        // slot of slice z is z % KS; the incoming slice s+M overwrites s-M-1
+                        lds[(c * KS + (s + M) % KS) * nt + tid] = prob[((int64_t)(s + M) * C + c) * HW + p];
+#pragma unroll
+                        for (int i = 0; i < KS; ++i) w[i] = lds[(c * KS + i) * nt + tid];
+                        v = median_regs<KS>(w);
+                        lds[(c * KS + s % KS) * nt + tid] = v;
+                    } else {
+                        v = (KS == 1) ? prob[((int64_t)s * C + c) * HW + p]
+                                      : lds[(c * KS + s % KS) * nt + tid];
+                    }
+                    if (out_prob) out_prob[((int64_t)s * C + c) * HW + p] = v;
+                    if (v > best) { best = v; arg = c; }
+                }
+                out_sem[(int64_t)s * HW + p] = (uint8_t)arg;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int KS>
+static int launch_median(const float *prob, int D, int C, int64_t HW, float thr, uint8_t *out_sem,
+                         float *out_prob, hipStream_t st)
+{
+    const int block = 256;
+    int grid = emp_grid(HW, block, 8192);
+    if (C == 1) {
+        hipLaunchKernelGGL(median_harden_c1_kernel<KS>, dim3(grid), dim3(block), 0, st, prob, D, HW, thr,
+                           out_sem, out_prob);
+    } else {
+        size_t lds = (size_t)C * KS * block * sizeof(float);
+        if (lds > 160 * 1024) EMP_FAIL(EMP_EINVAL, "median: C*ks too large for LDS (%d x %d)", C, KS);
+        if (lds > 64 * 1024)
+            hipFuncSetAttribute((const void *)median_harden_mc_kernel<KS>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(median_harden_mc_kernel<KS>, dim3(grid), dim3(block), lds, st, prob, D, C, HW,
+                           out_sem, out_prob);
+    }
+    EMP_CHECK_LAUNCH("emp_median_harden_stack");
+    return EMP_OK;
+}
+
+extern "C" int emp_median_harden_stack(const float *prob, int D, int C, int64_t HW, int ks, float thr,
+                                       uint8_t *out_sem, float *out_prob, void *stream)
+{
+    EMP_REQUIRE(prob && out_sem, "median: null pointer");
+    EMP_REQUIRE(D >= 0 && HW >= 0, "median: negative size");
+    EMP_REQUIRE(C >= 1 && C <= EMP_MAX_CLASSES, "median: C=%d out of range", C);
+    EMP_REQUIRE(ks >= 1 && ks <= EMP_MAX_KS && (ks & 1), "median: ks=%d must be odd in 1..%d", ks, EMP_MAX_KS);
+    EMP_REQUIRE(ks == 1 || D >= ks, "median: stack shorter than ks (D=%d, ks=%d): host must degrade", D, ks);
+    if (D == 0 || HW == 0) return EMP_OK;
+    hipStream_t st = emp_stream(stream);
+    switch (ks) {
+        case 1: return launch_median<1>(prob, D, C, HW, thr, out_sem, out_prob, st);
+        case 3: return launch_median<3>(prob, D, C, HW, thr, out_sem, out_prob, st);
+        case 5: return launch_median<5>(prob, D, C, HW, thr, out_sem, out_prob, st);
+        case 7: return launch_median<7>(prob, D, C, HW, thr, out_sem, out_prob, st);
+        case 9: return launch_median<9>(prob, D, C, HW, thr, out_sem, out_prob, st);
+        default: return launch_median<11>(prob, D, C, HW, thr, out_sem, out_prob, st);
+    }
+}
+
+extern "C" int emp_harden(const float *prob, int D, int C, int64_t HW, float thr, uint8_t *out_sem,
+                          void *stream)
+{
+    return emp_median_harden_stack(prob, D, C, HW, 1, thr, out_sem, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// streaming median step: ks slice pointers by value
+struct SlicePtrs { const float *p[EMP_MAX_KS]; };
+
+template <int KS>
+__global__ __launch_bounds__(256) void median_step_kernel(SlicePtrs sp, int64_t n, float *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float w[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) w[k] = sp.p[k][i];
+        out[i] = median_regs<KS>(w);
+    }
+}
+
+extern "C" int emp_median_step(const float *const *slices_host, int ks, int64_t n, float *out, void *stream)
+{
+    EMP_REQUIRE(slices_host && out, "median_step: null pointer");
+    EMP_REQUIRE(ks >= 1 && ks <= EMP_MAX_KS && (ks & 1), "median_step: ks=%d must be odd in 1..%d", ks, EMP_MAX_KS);
+    if (n <= 0) return EMP_OK;
+    SlicePtrs sp;
+    for (int k = 0; k < EMP_MAX_KS; ++k) sp.p[k] = slices_host[k < ks ? k : 0];
+    hipStream_t st = emp_stream(stream);
+    int grid = emp_grid(n, 256, 4096);
+#define EMP_MS(K) hipLaunchKernelGGL(median_step_kernel<K>, dim3(grid), dim3(256), 0, st, sp, n, out)
+    switch (ks) {
+        case 1: EMP_MS(1); break;
+        case 3: EMP_MS(3); break;
+        case 5: EMP_MS(5); break;
+        case 7: EMP_MS(7); break;
+        case 9: EMP_MS(9); break;
+        default: EMP_MS(11); break;
+    }
+#undef EMP_MS
+    EMP_CHECK_LAUNCH("emp_median_step");
+    return EMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// P3: centre NMS.  Block = 256 threads, output tile 16 x 64; the thresholded tile + halo is
+// staged in LDS, the k x k maximum is separable (row max, then column max).
+#define CT_H 16
+#define CT_W 64
+#define CT_MAXK 15
+
+__global__ __launch_bounds__(256) void find_centers_kernel(const float *__restrict__ hmp, int h, int w,
+                                                           float thr, int k, int cap,
+                                                           int32_t *__restrict__ out_idx,
+                                                           int32_t *__restrict__ out_count, int tiles_x)
+{
+    __shared__ float tile[(CT_H + CT_MAXK - 1) * (CT_W + CT_MAXK - 1)];
+    __shared__ float rowmax[(CT_H + CT_MAXK - 1) * CT_W];
+    const int d = blockIdx.y;
+    const int ty0 = (blockIdx.x / tiles_x) * CT_H;
+    const int tx0 = (blockIdx.x % tiles_x) * CT_W;
+    const int pad = k / 2;
+    const int th = CT_H + k - 1, tw = CT_W + k - 1;
+    const float *img = hmp + (int64_t)d * h * w;
+    for (int i = threadIdx.x; i < th * tw; i += blockDim.x) {
+        int ly = i / tw, lx = i % tw;
+        int y = ty0 - pad + ly, x = tx0 - pad + lx;
+        float v = -INFINITY;
+        if (y >= 0 && y < h && x >= 0 && x < w) {
+            v = img[(int64_t)y * w + x];
+            v = (v > thr) ? v : -1.0f;  // F.threshold(h, thr, -1)
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < th * CT_W; i += blockDim.x) {
+        int ly = i / CT_W, lx = i % CT_W;
+        float m = -INFINITY;
+        for (int j = 0; j < k; ++j) m = fmaxf(m, tile[ly * tw + lx + j]);
+        rowmax[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CT_H * CT_W; i += blockDim.x) {
+        int ly = i / CT_W, lx = i % CT_W;
+        int y = ty0 + ly, x = tx0 + lx;
+        if (y >= h || x >= w) continue;
+        float v = tile[(ly + pad) * tw + lx + pad];
+        if (!(v > 0.0f)) continue;
+        float m = -INFINITY;
+        for (int j = 0; j < k; ++j) m = fmaxf(m, rowmax[(ly + j) * CT_W + lx]);
+        if (v == m) {
+            int slot = atomicAdd(&out_count[d], 1);
+            if (slot < cap) out_idx[(int64_t)d * cap + slot] = y * w + x;
+        }
+    }
+}
+
+// per-slice bitonic sort of the (few) centre indices -> raster order
+__global__ __launch_bounds__(256) void sort_centers_kernel(int32_t *__restrict__ idx,
+                                                           const int32_t *__restrict__ count, int cap)
+{
+    __shared__ int32_t buf[EMP_MAX_CENTERS];
+    const int d = blockIdx.x;
+    int n = count[d];
+    if (n > cap) n = cap;
+    if (n <= 1) return;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    int32_t *g = idx + (int64_t)d * cap;
+    for (int i = threadIdx.x; i < np2; i += blockDim.x) buf[i] = (i < n) ? g[i] : 0x7fffffff;
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < np2 / 2; i += blockDim.x) {
+                int lo = (i / stride) * 2 * stride + (i % stride);
+                int hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                int32_t a = buf[lo], b = buf[hi];
+                if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = buf[i];
+}
+
+extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr, int k, int cap,
+                                int32_t *out_idx, int32_t *out_count, void *stream)
+{
+    EMP_REQUIRE(hmp && out_idx && out_count, "find_centers: null pointer");
+    EMP_REQUIRE(k >= 1 && k <= CT_MAXK, "find_centers: nms kernel %d not in 1..%d", k, CT_MAXK);
+    EMP_REQUIRE(cap >= 1 && cap <= EMP_MAX_CENTERS, "find_centers: cap %d not in 1..%d", cap, EMP_MAX_CENTERS);
+    EMP_REQUIRE(D >= 0 && D <= 65535 && h > 0 && w > 0, "find_centers: bad shape D=%d h=%d w=%d", D, h, w);
+    EMP_REQUIRE((int64_t)h * w < (1LL << 31), "find_centers: slice too large");
+    if (D == 0) return EMP_OK;
+    hipStream_t st = emp_stream(stream);
+    if (hipMemsetAsync(out_count, 0, sizeof(int32_t) * D, st) != hipSuccess)
+        EMP_FAIL(EMP_ELAUNCH, "find_centers: memset failed");
+    int tiles_x = (w + CT_W - 1) / CT_W, tiles_y = (h + CT_H - 1) / CT_H;
+    hipLaunchKernelGGL(find_centers_kernel, dim3(tiles_x * tiles_y, D), dim3(256), 0, st, hmp, h, w, thr, k,
+                       cap, out_idx, out_count, tiles_x);
+    EMP_CHECK_LAUNCH("emp_find_centers");
+    hipLaunchKernelGGL(sort_centers_kernel, dim3(D), dim3(256), 0, st, out_idx, out_count, cap);
+    EMP_CHECK_LAUNCH("emp_find_centers(sort)");
+    return EMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// P4: nearest-centre vote.  Block = 256 threads x GP_PPT pixels of one slice; the slice's centres
+// sit in LDS (broadcast reads).  Exact rounding contract (see emp_hip.h):
+//   s = fmaf(dx, dx, fl(dy*dy)); d = sqrt_rn(s); first strictly smaller d wins.
+// sqrt is monotone, so d is only evaluated when s improves on the best s so far.
+#define GP_PPT 4
+
+__global__ __launch_bounds__(256) void group_pixels_kernel(const int32_t *__restrict__ ctr_idx,
+                                                           const int32_t *__restrict__ ctr_count, int cap,
+                                                           const float *__restrict__ offsets, int h, int w,
+                                                           int step, uint16_t *__restrict__ out_ids)
+{
+    __shared__ float2 ctr[EMP_MAX_CENTERS];
+    const int d = blockIdx.y;
+    int K = ctr_count[d];
+    if (K > cap) K = cap;
+    const int64_t hw = (int64_t)h * w;
+    const float fstep = (float)step;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        int f = ctr_idx[(int64_t)d * cap + i];
+        // step * ctr: int64 * python float -> fp32 tensor (postprocess.py:151)
+        ctr[i] = make_float2(__fmul_rn(fstep, (float)(f / w)), __fmul_rn(fstep, (float)(f % w)));
+    }
+    __syncthreads();
+    const float *offy = offsets + (int64_t)d * 2 * hw;
+    const float *offx = offy + hw;
+    uint16_t *out = out_ids + (int64_t)d * hw;
+    const float dinit = (K > 20) ? 1e5f : INFINITY;
+    const int idinit = (K > 20 || K == 0) ? 0 : 1;
+    int64_t base = ((int64_t)blockIdx.x * blockDim.x) * GP_PPT + threadIdx.x;
+    float ly[GP_PPT], lx[GP_PPT], sb[GP_PPT], db[GP_PPT];
+    int id[GP_PPT];
+#pragma unroll
+    for (int j = 0; j < GP_PPT; ++j) {
+        int64_t p = base + (int64_t)j * blockDim.x;
+        bool live = p < hw;
+        int y = live ? (int)(p / w) : 0, x = live ? (int)(p % w) : 0;
+        float oy = live ? offy[p] : 0.f, ox = live ? offx[p] : 0.f;
+        ly[j] = __fadd_rn((float)(y * step), oy);  // coord + offsets
+        lx[j] = __fadd_rn((float)(x * step), ox);
+        sb[j] = INFINITY;
+        db[j] = dinit;
+        id[j] = idinit;
+    }
+    for (int k = 0; k < K; ++k) {
+        float2 c = ctr[k];
+#pragma unroll
+        for (int j = 0; j < GP_PPT; ++j) {
+            float dy = __fsub_rn(c.x, ly[j]);
+            float dx = __fsub_rn(c.y, lx[j]);
+            float s = __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
+            if (s < sb[j]) {
+                sb[j] = s;
+                float dd = __fsqrt_rn(s);
+                if (dd < db[j]) { db[j] = dd; id[j] = k + 1; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < GP_PPT; ++j) {
+        int64_t p = base + (int64_t)j * blockDim.x;
+        if (p < hw) out[p] = (uint16_t)id[j];
+    }
+}
+
+extern "C" int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count, int cap,
+                                const float *offsets, int D, int h, int w, int step, uint16_t *out_ids,
+                                void *stream)
+{
+    EMP_REQUIRE(ctr_idx && ctr_count && offsets && out_ids, "group_pixels: null pointer");
+    EMP_REQUIRE(cap >= 1 && cap <= EMP_MAX_CENTERS, "group_pixels: cap %d not in 1..%d", cap, EMP_MAX_CENTERS);
+    EMP_REQUIRE(step == 1 || step == 4, "group_pixels: step must be 1 or 4");
+    EMP_REQUIRE(D >= 0 && D <= 65535 && h > 0 && w > 0, "group_pixels: bad shape");
+    EMP_REQUIRE((int64_t)h * step < (1 << 24) && (int64_t)w * step < (1 << 24), "group_pixels: coords exceed fp32 integers");
+    if (D == 0) return EMP_OK;
+    int64_t hw = (int64_t)h * w;
+    int gx = (int)emp_cdiv(hw, 256 * GP_PPT);
+    hipLaunchKernelGGL(group_pixels_kernel, dim3(gx, D), dim3(256), 0, emp_stream(stream), ctr_idx, ctr_count,
+                       cap, offsets, h, w, step, out_ids);
+    EMP_CHECK_LAUNCH("emp_group_pixels");
+    return EMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// P4b + P5: fuse semantic classes with instance cells.
+// work layout (int32): hist[D][cap+1][NC] | stuff[D][NC] | lut[D][cap+1] (pan value as u32) |
+//                      stuff_ok[D][NC]
+struct FuseLayout {
+    int64_t hist, stuff, lut, ok, total;
+};
+static inline FuseLayout fuse_layout(int D, int cap, int nc)
+{
+    FuseLayout L;
+    L.hist = 0;
+    L.stuff = L.hist + (int64_t)D * (cap + 1) * nc;
+    L.lut = L.stuff + (int64_t)D * nc;
+    L.ok = L.lut + (int64_t)D * (cap + 1);
+    L.total = L.ok + (int64_t)D * nc;
+    return L;
+}
+extern "C" int64_t emp_fuse_work_elems(int D, int cap, int n_classes)
+{
+    return fuse_layout(D, cap, n_classes).total;
+}
+
+// wave-aggregated histogram increment: lanes holding the same key as their left neighbour are
+// folded into the run head, which adds the run length with one atomic.
+__device__ __forceinline__ void wave_hist_add(int32_t *base, int64_t key, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    int64_t prev = __shfl_up(key, 1);
+    bool pvalid = __shfl_up((int)valid, 1) != 0;
+    bool head = valid && (lane == 0 || !pvalid || prev != key);
+    unsigned long long heads = __ballot(head);
+    unsigned long long valids = __ballot(valid);
+    if (head) {
+        // run ends at the next head or the first invalid lane after this one
+        unsigned long long stop = (heads | ~valids) & ~((2ULL << lane) - 1ULL);
+        int end = stop ? __ffsll((long long)stop) - 1 : 64;
+        atomicAdd(base + key, end - lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void fuse_hist_kernel(const uint8_t *__restrict__ sem,
+                                                        const uint16_t *__restrict__ ids, int H, int W, int up,
+                                                        int cap, int nc, uint32_t thing_mask,
+                                                        int32_t *__restrict__ hist, int32_t *__restrict__ stuff)
+{
+    const int d = blockIdx.y;
+    const int64_t HW = (int64_t)H * W;
+    const int w = W / up;
+    const uint8_t *s = sem + (int64_t)d * HW;
+    const uint16_t *g = ids + (int64_t)d * (H / up) * w;
+    int32_t *hh = hist + (int64_t)d * (cap + 1) * nc;
+    int32_t *ss = stuff + (int64_t)d * nc;
+    // whole waves iterate together so that the ballots see uniform control flow
+    int64_t span = (int64_t)gridDim.x * blockDim.x;
+    int64_t iters = (HW + span - 1) / span;
+    for (int64_t it = 0; it < iters; ++it) {
+        int64_t p = it * span + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        bool live = p < HW;
+        int c = 0, ins = 0;
+        if (live) {
+            c = s[p];
+            if (c >= nc) c = nc - 1;
+            int y = (int)(p / W), x = (int)(p % W);
+            int id = g[(int64_t)(y / up) * w + x / up];
+            ins = ((thing_mask >> c) & 1u) ? id : 0;
+        }
+        wave_hist_add(hh, (int64_t)ins * nc + c, live && ins > 0);
+        wave_hist_add(ss, (int64_t)c, live && ins == 0);
+    }
+}
+
+// one block per slice: majority class per instance, per-class renumbering (block scan), stuff areas
+__global__ __launch_bounds__(256) void fuse_lut_kernel(int cap, int nc, uint32_t thing_mask, int64_t div,
+                                                       int64_t stuff_area, const int32_t *__restrict__ hist,
+                                                       const int32_t *__restrict__ stuff,
+                                                       int32_t *__restrict__ lut, int32_t *__restrict__ ok)
+{
+    __shared__ int32_t scan[256];
+    __shared__ int32_t carry[EMP_MAX_CLASSES];
+    const int d = blockIdx.x;
+    const int32_t *hh = hist + (int64_t)d * (cap + 1) * nc;
+    uint32_t *ll = reinterpret_cast<uint32_t *>(lut) + (int64_t)d * (cap + 1);
+    if (threadIdx.x < EMP_MAX_CLASSES) carry[threadIdx.x] = 0;
+    if (threadIdx.x < nc) {
+        bool thing = (thing_mask >> threadIdx.x) & 1u;
+        ok[(int64_t)d * nc + threadIdx.x] = (!thing && stuff[(int64_t)d * nc + threadIdx.x] >= stuff_area) ? 1 : 0;
+    }
+    __syncthreads();
+    for (int base = 1; base <= cap; base += blockDim.x) {
+        int id = base + threadIdx.x;
+        int mode = -1;
+        if (id <= cap) {
+            int best = 0;
+            for (int c = 0; c < nc; ++c) {
+                int n = hh[(int64_t)id * nc + c];
+                if (n > best) { best = n; mode = c; }  // ties -> smallest class (torch.mode)
+            }
+        }
+        for (int c = 0; c < nc; ++c) {
+            if (!((thing_mask >> c) & 1u)) continue;
+            int flag = (mode == c) ? 1 : 0;
+            scan[threadIdx.x] = flag;
+            __syncthreads();
+            for (int off = 1; off < blockDim.x; off <<= 1) {
+                int v = (threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
+                __syncthreads();
+                scan[threadIdx.x] += v;
+                __syncthreads();
+            }
+            int incl = scan[threadIdx.x];
+            int total = scan[blockDim.x - 1];
+            if (flag) ll[id] = (uint32_t)((int64_t)c * div + carry[c] + incl);
+            __syncthreads();
+            if (threadIdx.x == 0) carry[c] += total;
+            __syncthreads();
+        }
+    }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void fuse_apply_kernel(const uint8_t *__restrict__ sem,
+                                                         const uint16_t *__restrict__ ids, int H, int W, int up,
+                                                         int cap, int nc, uint32_t thing_mask, int64_t div,
+                                                         int64_t void_label, const int32_t *__restrict__ lut,
+                                                         const int32_t *__restrict__ ok, OutT *__restrict__ out)
+{
+    const int d = blockIdx.y;
+    const int64_t HW = (int64_t)H * W;
+    const int w = W / up;
+    const uint8_t *s = sem + (int64_t)d * HW;
+    const uint16_t *g = ids + (int64_t)d * (H / up) * w;
+    const uint32_t *ll = reinterpret_cast<const uint32_t *>(lut) + (int64_t)d * (cap + 1);
+    const int32_t *oo = ok + (int64_t)d * nc;
+    OutT *o = out + (int64_t)d * HW;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < HW;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        int c = s[p];
+        if (c >= nc) c = nc - 1;
+        int y = (int)(p / W), x = (int)(p % W);
+        int id = g[(int64_t)(y / up) * w + x / up];
+        int ins = ((thing_mask >> c) & 1u) ? id : 0;
+        int64_t v;
+        if (ins > 0) v = (int64_t)ll[ins];
+        else v = oo[c] ? (int64_t)c * div : void_label;
+        o[p] = (OutT)v;
+    }
+}
+
+extern "C" int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D, int H, int W, int up, int cap,
+                                 int n_classes, uint32_t thing_mask, int64_t label_divisor, int64_t stuff_area,
+                                 int64_t void_label, int32_t *work, uint32_t *out_pan_u32,
+                                 int64_t *out_pan_i64, void *stream)
+{
+    EMP_REQUIRE(sem && ids && work, "fuse: null pointer");
+    EMP_REQUIRE((out_pan_u32 != nullptr) != (out_pan_i64 != nullptr), "fuse: exactly one output must be given");
+    EMP_REQUIRE(up >= 1 && H % up == 0 && W % up == 0, "fuse: H,W must be multiples of up=%d", up);
+    EMP_REQUIRE(n_classes >= 1 && n_classes <= EMP_MAX_CLASSES, "fuse: n_classes out of range");
+    EMP_REQUIRE(cap >= 1 && cap <= 65535, "fuse: cap out of range");
+    EMP_REQUIRE(D >= 0 && D <= 65535 && H > 0 && W > 0, "fuse: bad shape");
+    EMP_REQUIRE(label_divisor > 0 && (n_classes * label_divisor) < (1LL << 32), "fuse: labels exceed 32 bits");
+    if (D == 0) return EMP_OK;
+    hipStream_t st = emp_stream(stream);
+    FuseLayout L = fuse_layout(D, cap, n_classes);
+    if (hipMemsetAsync(work, 0, sizeof(int32_t) * L.total, st) != hipSuccess)
+        EMP_FAIL(EMP_ELAUNCH, "fuse: memset failed");
+    int64_t HW = (int64_t)H * W;
+    int gx = emp_grid(HW, 256, 1024);
+    hipLaunchKernelGGL(fuse_hist_kernel, dim3(gx, D), dim3(256), 0, st, sem, ids, H, W, up, cap, n_classes,
+                       thing_mask, work + L.hist, work + L.stuff);
+    EMP_CHECK_LAUNCH("emp_fuse_panoptic(hist)");
+    hipLaunchKernelGGL(fuse_lut_kernel, dim3(D), dim3(256), 0, st, cap, n_classes, thing_mask, label_divisor,
+                       stuff_area, work + L.hist, work + L.stuff, work + L.lut, work + L.ok);
+    EMP_CHECK_LAUNCH("emp_fuse_panoptic(lut)");
+    if (out_pan_u32)
+        hipLaunchKernelGGL(fuse_apply_kernel<uint32_t>, dim3(gx, D), dim3(256), 0, st, sem, ids, H, W, up, cap,
+                           n_classes, thing_mask, label_divisor, void_label, work + L.lut, work + L.ok,
+                           out_pan_u32);
+    else
+        hipLaunchKernelGGL(fuse_apply_kernel<int64_t>, dim3(gx, D), dim3(256), 0, st, sem, ids, H, W, up, cap,
+                           n_classes, thing_mask, label_divisor, void_label, work + L.lut, work + L.ok,
+                           out_pan_i64);
+    EMP_CHECK_LAUNCH("emp_fuse_panoptic(apply)");
+    return EMP_OK;
+}

@@ -1,0 +1,304 @@
+// Range-level kernels: stable radix sort of run tables (rocPRIM through hipCUB), coverage voting /
+// joining of ranges (C3), exact pairwise RLE intersection sweep (M2/C1) and volume fill (R4/Z1).
+#include "emp_common.h"
+
+#include <hipcub/hipcub.hpp>
+
+extern "C" int emp_exclusive_scan_i32(const int32_t *in, int64_t n, int32_t *out, int32_t *tmp, void *stream);
+extern "C" int64_t emp_scan_tmp_elems(int64_t n);
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------
+extern "C" int64_t emp_sort_work_bytes(int64_t n)
+{
+    size_t bytes = 0;
+    if (n < 1) n = 1;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                           (const int32_t *)nullptr, (int32_t *)nullptr, (int)n, 0, 64,
+                                           (hipStream_t)0) != hipSuccess)
+        return -1;
+    return (int64_t)align_up((int64_t)bytes, 256) + 256;
+}
+
+extern "C" int emp_sort_u64_i32(const uint64_t *keys_in, uint64_t *keys_out, const int32_t *vals_in,
+                                int32_t *vals_out, int64_t n, int begin_bit, int end_bit, void *work,
+                                int64_t work_bytes, void *stream)
+{
+    EMP_REQUIRE(n >= 0 && n < (1LL << 31), "sort: bad n");
+    if (n == 0) return EMP_OK;
+    EMP_REQUIRE(keys_in && keys_out && vals_in && vals_out && work, "sort: null pointer");
+    EMP_REQUIRE(begin_bit >= 0 && end_bit <= 64 && begin_bit < end_bit, "sort: bad bit range");
+    size_t need = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (int)n, begin_bit,
+                                       end_bit, emp_stream(stream));
+    EMP_REQUIRE((int64_t)need <= work_bytes, "sort: workspace too small (%lld < %zu)", (long long)work_bytes, need);
+    size_t wb = (size_t)work_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(work, wb, keys_in, keys_out, vals_in, vals_out, (int)n,
+                                                      begin_bit, end_bit, emp_stream(stream));
+    if (e != hipSuccess) EMP_FAIL(EMP_ELAUNCH, "sort: %s", hipGetErrorString(e));
+    return EMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// C3 voting by coverage count.  Events: (+1 at start, -1 at end), key = group<<41 | pos<<1 | type.
+struct VoteWork {
+    int64_t keys_in, keys_out, vals_in, vals_out, cov, flag_s, flag_e, scan_s, scan_e, scantmp, cub, cub_bytes, total;
+};
+static VoteWork vote_layout(int64_t n)
+{
+    VoteWork L;
+    int64_t m = 2 * (n > 0 ? n : 1);
+    int64_t o = 0;
+    L.keys_in = o; o += align_up(m * 8, 256);
+    L.keys_out = o; o += align_up(m * 8, 256);
+    L.vals_in = o; o += align_up(m * 4, 256);
+    L.vals_out = o; o += align_up(m * 4, 256);
+    L.cov = o; o += align_up((m + 1) * 4, 256);
+    L.flag_s = o; o += align_up(m * 4, 256);
+    L.flag_e = o; o += align_up(m * 4, 256);
+    L.scan_s = o; o += align_up((m + 1) * 4, 256);
+    L.scan_e = o; o += align_up((m + 1) * 4, 256);
+    L.scantmp = o; o += align_up(emp_scan_tmp_elems(m) * 4, 256);
+    L.cub = o;
+    L.cub_bytes = emp_sort_work_bytes(m);
+    o += L.cub_bytes;
+    L.total = o;
+    return L;
+}
+extern "C" int64_t emp_vote_work_bytes(int64_t n) { return vote_layout(n).total; }
+
+#define VOTE_POS_BITS 40
+#define VOTE_GRP_SHIFT (VOTE_POS_BITS + 1)
+
+__global__ void vote_events_kernel(const int64_t *__restrict__ starts, const int64_t *__restrict__ ends,
+                                   const int32_t *__restrict__ grp, int64_t n, uint64_t *__restrict__ keys,
+                                   int32_t *__restrict__ vals)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t g = (uint64_t)grp[i] << VOTE_GRP_SHIFT;
+        keys[2 * i] = g | ((uint64_t)starts[i] << 1);
+        vals[2 * i] = 1;
+        keys[2 * i + 1] = g | ((uint64_t)ends[i] << 1) | 1ULL;
+        vals[2 * i + 1] = -1;
+    }
+}
+
+__global__ void vote_flags_kernel(const uint64_t *__restrict__ keys, const int32_t *__restrict__ cov, int64_t m,
+                                  int thr, int32_t *__restrict__ flag_s, int32_t *__restrict__ flag_e)
+{
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < m; f += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t pos = keys[f] >> 1;
+        int fs = 0, fe = 0;
+        if (f == 0 || (keys[f - 1] >> 1) != pos) {  // first event at this (group, position)
+            int64_t i = f;
+            while (i + 1 < m && (keys[i + 1] >> 1) == pos) ++i;
+            int before = cov[f], after = cov[i + 1];
+            fs = (before < thr && after >= thr);
+            fe = (before >= thr && after < thr);
+        }
+        flag_s[f] = fs;
+        flag_e[f] = fe;
+    }
+}
+
+__global__ void vote_emit_kernel(const uint64_t *__restrict__ keys, int64_t m, const int32_t *__restrict__ flag_s,
+                                 const int32_t *__restrict__ flag_e, const int32_t *__restrict__ scan_s,
+                                 const int32_t *__restrict__ scan_e, int64_t *__restrict__ out_ranges)
+{
+    const uint64_t pos_mask = (1ULL << VOTE_POS_BITS) - 1ULL;
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < m; f += (int64_t)gridDim.x * blockDim.x) {
+        int64_t pos = (int64_t)((keys[f] >> 1) & pos_mask);
+        if (flag_s[f]) out_ranges[2 * (int64_t)scan_s[f] + 0] = pos;
+        if (flag_e[f]) out_ranges[2 * (int64_t)scan_e[f] + 1] = pos;
+    }
+}
+
+__global__ void vote_offsets_kernel(const uint64_t *__restrict__ keys, int64_t m, const int32_t *__restrict__ scan_s,
+                                    int n_groups, int32_t *__restrict__ out_off)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_groups) return;
+    uint64_t key = (uint64_t)g << VOTE_GRP_SHIFT;
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    out_off[g] = scan_s[lo];
+}
+
+extern "C" int emp_vote_ranges(const int64_t *starts, const int64_t *ends, const int32_t *grp, int64_t n,
+                               int n_groups, int vote_thr, void *work, int64_t work_bytes, int64_t *out_ranges,
+                               int32_t *out_off, void *stream)
+{
+    EMP_REQUIRE(out_off, "vote: null out_off");
+    EMP_REQUIRE(n >= 0 && n < (1LL << 29), "vote: bad n");
+    EMP_REQUIRE(n_groups >= 0 && n_groups < (1 << 22), "vote: too many groups");
+    EMP_REQUIRE(vote_thr >= 1, "vote: vote_thr must be >= 1");
+    hipStream_t st = emp_stream(stream);
+    if (n == 0) {
+        if (hipMemsetAsync(out_off, 0, sizeof(int32_t) * (n_groups + 1), st) != hipSuccess)
+            EMP_FAIL(EMP_ELAUNCH, "vote: memset");
+        return EMP_OK;
+    }
+    EMP_REQUIRE(starts && ends && grp && work && out_ranges, "vote: null pointer");
+    VoteWork L = vote_layout(n);
+    EMP_REQUIRE(work_bytes >= L.total, "vote: workspace too small");
+    char *w = reinterpret_cast<char *>(work);
+    uint64_t *keys_in = reinterpret_cast<uint64_t *>(w + L.keys_in);
+    uint64_t *keys_out = reinterpret_cast<uint64_t *>(w + L.keys_out);
+    int32_t *vals_in = reinterpret_cast<int32_t *>(w + L.vals_in);
+    int32_t *vals_out = reinterpret_cast<int32_t *>(w + L.vals_out);
+    int32_t *cov = reinterpret_cast<int32_t *>(w + L.cov);
+    int32_t *flag_s = reinterpret_cast<int32_t *>(w + L.flag_s);
+    int32_t *flag_e = reinterpret_cast<int32_t *>(w + L.flag_e);
+    int32_t *scan_s = reinterpret_cast<int32_t *>(w + L.scan_s);
+    int32_t *scan_e = reinterpret_cast<int32_t *>(w + L.scan_e);
+    int32_t *scantmp = reinterpret_cast<int32_t *>(w + L.scantmp);
+    int64_t m = 2 * n;
+    int grid = emp_grid(m, 256, 4096);
+    hipLaunchKernelGGL(vote_events_kernel, dim3(grid), dim3(256), 0, st, starts, ends, grp, n, keys_in, vals_in);
+    EMP_CHECK_LAUNCH("emp_vote_ranges(events)");
+    int rc = emp_sort_u64_i32(keys_in, keys_out, vals_in, vals_out, m, 0, 64, w + L.cub, L.cub_bytes, stream);
+    if (rc != EMP_OK) return rc;
+    rc = emp_exclusive_scan_i32(vals_out, m, cov, scantmp, stream);
+    if (rc != EMP_OK) return rc;
+    hipLaunchKernelGGL(vote_flags_kernel, dim3(grid), dim3(256), 0, st, keys_out, cov, m, vote_thr, flag_s, flag_e);
+    EMP_CHECK_LAUNCH("emp_vote_ranges(flags)");
+    rc = emp_exclusive_scan_i32(flag_s, m, scan_s, scantmp, stream);
+    if (rc != EMP_OK) return rc;
+    rc = emp_exclusive_scan_i32(flag_e, m, scan_e, scantmp, stream);
+    if (rc != EMP_OK) return rc;
+    hipLaunchKernelGGL(vote_emit_kernel, dim3(grid), dim3(256), 0, st, keys_out, m, flag_s, flag_e, scan_s, scan_e,
+                       out_ranges);
+    hipLaunchKernelGGL(vote_offsets_kernel, dim3((unsigned)emp_cdiv(n_groups + 1, 256)), dim3(256), 0, st, keys_out,
+                       m, scan_s, n_groups, out_off);
+    EMP_CHECK_LAUNCH("emp_vote_ranges");
+    return EMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// exact pairwise sweep (array_utils.py:340-403): stable merge by start (A before B on ties); the
+// run that precedes the latest source change is the "check run"; every following run that starts
+// at or before its end contributes min(ends) - max(starts).
+__global__ void pair_intersections_kernel(const int64_t *__restrict__ starts, const int64_t *__restrict__ lens,
+                                          const int64_t *__restrict__ inst_off, const int32_t *__restrict__ pairs,
+                                          int64_t n_pairs, int64_t *__restrict__ out)
+{
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        int a = pairs[2 * p], b = pairs[2 * p + 1];
+        int64_t ia = inst_off[a], ea = inst_off[a + 1];
+        int64_t ib = inst_off[b], eb = inst_off[b + 1];
+        int64_t total = 0;
+        bool have_prev = false, have_chk = false;
+        int prev_src = 0;
+        int64_t prev_s = 0, prev_e = 0, chk_s = 0, chk_e = 0;
+        while (ia < ea || ib < eb) {
+            int src;
+            if (ib >= eb) src = 0;
+            else if (ia >= ea) src = 1;
+            else src = (starts[ia] <= starts[ib]) ? 0 : 1;
+            int64_t s, e;
+            if (src == 0) { s = starts[ia]; e = s + lens[ia]; ++ia; }
+            else { s = starts[ib]; e = s + lens[ib]; ++ib; }
+            if (have_prev) {
+                if (src != prev_src) { chk_s = prev_s; chk_e = prev_e; have_chk = true; }
+                if (have_chk && !(chk_e < s)) {
+                    int64_t hi = chk_e < e ? chk_e : e;
+                    int64_t lo = chk_s > s ? chk_s : s;
+                    total += hi - lo;
+                }
+            }
+            prev_s = s; prev_e = e; prev_src = src; have_prev = true;
+        }
+        out[p] = total;
+    }
+}
+
+extern "C" int emp_rle_pair_intersections(const int64_t *starts, const int64_t *lens, const int64_t *inst_off,
+                                          const int32_t *pairs, int64_t n_pairs, int64_t *out_inter, void *stream)
+{
+    EMP_REQUIRE(n_pairs >= 0, "pair_intersections: bad n_pairs");
+    if (n_pairs == 0) return EMP_OK;
+    EMP_REQUIRE(starts && lens && inst_off && pairs && out_inter, "pair_intersections: null pointer");
+    int grid = emp_grid(n_pairs, 64, 8192);
+    hipLaunchKernelGGL(pair_intersections_kernel, dim3(grid), dim3(64), 0, emp_stream(stream), starts, lens, inst_off,
+                       pairs, n_pairs, out_inter);
+    EMP_CHECK_LAUNCH("emp_rle_pair_intersections");
+    return EMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fill: one wave per run, lanes stride along the run (coalesced 256-B stores).
+// pass 1 tags voxels with the highest instance order covering them, pass 2 turns tags into ids.
+#define FILL_TAG 0x80000000u
+
+template <int PASS>
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *__restrict__ vol, int64_t n_vox,
+                                                       const int64_t *__restrict__ starts,
+                                                       const int64_t *__restrict__ lens,
+                                                       const int32_t *__restrict__ order, int64_t n_runs,
+                                                       const uint32_t *__restrict__ ids)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_runs; r += n_waves) {
+        int64_t s = starts[r], e = s + lens[r];
+        if (s < 0) s = 0;
+        if (e > n_vox) e = n_vox;
+        uint32_t tag = FILL_TAG | (uint32_t)order[r];
+        for (int64_t v = s + lane; v < e; v += 64) {
+            if (PASS == 0) {
+                atomicMax(&vol[v], tag);
+            } else {
+                uint32_t cur = vol[v];
+                if (cur & FILL_TAG) vol[v] = ids[cur & ~FILL_TAG];
+            }
+        }
+    }
+}
+
+extern "C" int emp_fill_runs_u32(uint32_t *vol, int64_t n_vox, const int64_t *starts, const int64_t *lens,
+                                 const int32_t *order, int64_t n_runs, const uint32_t *ids, void *stream)
+{
+    EMP_REQUIRE(n_runs >= 0 && n_vox >= 0, "fill: bad sizes");
+    if (n_runs == 0) return EMP_OK;
+    EMP_REQUIRE(vol && starts && lens && order && ids, "fill: null pointer");
+    int grid = emp_grid(n_runs * 64, 256, 8192);
+    hipStream_t st = emp_stream(stream);
+    hipLaunchKernelGGL(fill_u32_kernel<0>, dim3(grid), dim3(256), 0, st, vol, n_vox, starts, lens, order, n_runs, ids);
+    hipLaunchKernelGGL(fill_u32_kernel<1>, dim3(grid), dim3(256), 0, st, vol, n_vox, starts, lens, order, n_runs, ids);
+    EMP_CHECK_LAUNCH("emp_fill_runs_u32");
+    return EMP_OK;
+}
+
+__global__ __launch_bounds__(256) void fill_u8_kernel(uint8_t *__restrict__ vol, int64_t n_vox,
+                                                      const int64_t *__restrict__ starts,
+                                                      const int64_t *__restrict__ lens, int64_t n_runs, uint8_t value)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_runs; r += n_waves) {
+        int64_t s = starts[r], e = s + lens[r];
+        if (s < 0) s = 0;
+        if (e > n_vox) e = n_vox;
+        for (int64_t v = s + lane; v < e; v += 64) vol[v] = value;
+    }
+}
+
+extern "C" int emp_fill_runs_u8(uint8_t *vol, int64_t n_vox, const int64_t *starts, const int64_t *lens,
+                                int64_t n_runs, uint8_t value, void *stream)
+{
+    EMP_REQUIRE(n_runs >= 0 && n_vox >= 0, "fill_u8: bad sizes");
+    if (n_runs == 0) return EMP_OK;
+    EMP_REQUIRE(vol && starts && lens, "fill_u8: null pointer");
+    int grid = emp_grid(n_runs * 64, 256, 8192);
+    hipLaunchKernelGGL(fill_u8_kernel, dim3(grid), dim3(256), 0, emp_stream(stream), vol, n_vox, starts, lens, n_runs,
+                       value);
+    EMP_CHECK_LAUNCH("emp_fill_runs_u8");
+    return EMP_OK;
+}

@@ -1,0 +1,196 @@
+/*
+ * emp_hip.h -- C ABI of libemp_hip.so, the MI355X (gfx950) implementation of empanada's
+ * orthoplane-inference post-processing hot path.
+ *
+ * The reference (volume-em/empanada) is 100 % Python: it has no FFI.  This ABI is therefore
+ * NEW surface; each entry point names the reference function(s) (path:line relative to the
+ * reference root) whose arithmetic it replaces.  The Python package `empanada_amd` binds these
+ * with ctypes (empanada_amd/_hip.py) behind the reference's own engine / matcher / tracker
+ * names; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and never allocates, frees or synchronises, so callers may capture it in a
+ *     hipGraph.  Workspaces are caller-provided.
+ *   - return value: 0 on success, negative EMP_E* on error; emp_last_error() returns a
+ *     per-thread message.  No exceptions cross the boundary.
+ *   - images are row-major; a "stack" is D slices of (H, W); "HW" = H*W.
+ *   - labels: pan = class_id * label_divisor + instance_id (reference convention).
+ */
+#ifndef EMP_HIP_H
+#define EMP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMP_OK 0
+#define EMP_EINVAL (-1)   /* bad argument (shape, size, unsupported parameter) */
+#define EMP_ELAUNCH (-2)  /* HIP launch / runtime error */
+#define EMP_ENODEV (-3)   /* no usable gfx950 device */
+
+#define EMP_MAX_KS 11       /* median kernel sizes 1,3,...,11 (reference: scripts/pdl_inference3d.py:28) */
+#define EMP_MAX_CLASSES 16  /* semantic channels C, and class ids < 16 */
+#define EMP_MAX_CENTERS 4096 /* per-slice centre capacity the in-LDS sort supports */
+
+int emp_version(void);
+const char *emp_last_error(void);
+/* Number of visible HIP devices (does not create a context). */
+int emp_device_count(void);
+
+/* ---- P1 + P2: recursive median over a resident stack, fused with hardening ----------------
+ * replaces _MedianQueue.get_next/get_median/end   empanada/inference/engines.py:47-90
+ *          _harden_seg / harden_seg               engines.py:114-121, inference/patterns.py:242-251
+ * prob  (D, C, HW) fp32 probabilities.  For slice s in [m, D-m) (m = ks/2) the output is the
+ * median of {out[s-m..s-1], prob[s..s+m]} (the reference writes the median back into its queue,
+ * which makes the filter recursive); the first and last m slices pass through.  Requires
+ * D >= ks or ks == 1 (the reference loses slices for shorter stacks; the host mirrors that).
+ * out_sem (D, HW) u8: C == 1 -> (p >= thr), C > 1 -> argmax over the filtered channels.
+ * out_prob (D, C, HW) fp32 or NULL: the filtered probabilities.                                */
+int emp_median_harden_stack(const float *prob, int D, int C, int64_t HW, int ks, float thr,
+                            uint8_t *out_sem, float *out_prob, void *stream);
+
+/* One streaming step of the same filter: median over ks slices of n floats each.
+ * slices_host: host array of ks device pointers; out may alias any of them.
+ * replaces _MedianQueue.get_median                 engines.py:59-66                             */
+int emp_median_step(const float *const *slices_host, int ks, int64_t n, float *out, void *stream);
+
+/* Harden only (no median).  prob (D, C, HW) -> out_sem (D, HW) u8.                              */
+int emp_harden(const float *prob, int D, int C, int64_t HW, float thr, uint8_t *out_sem,
+               void *stream);
+
+/* ---- P3: centre detection ------------------------------------------------------------------
+ * replaces find_instance_center                    empanada/inference/postprocess.py:38-76
+ * hmp (D, h, w) fp32.  A pixel is a centre when v > thr, v > 0 and v equals the maximum of
+ * threshold(v) over the k x k window rows y-k/2 .. y-k/2+k-1 (same for x; -inf padding).
+ * out_idx (D, cap) int32 flat indices y*w+x, ascending (raster order) per slice;
+ * out_count (D) int32 = number found (may exceed cap: then only `cap` are stored, unordered
+ * selection -- the caller must treat count > cap as an error).  cap <= EMP_MAX_CENTERS.         */
+int emp_find_centers(const float *hmp, int D, int h, int w, float thr, int k, int cap,
+                     int32_t *out_idx, int32_t *out_count, void *stream);
+
+/* ---- P4: nearest-centre pixel grouping -----------------------------------------------------
+ * replaces group_pixels / chunked_pixel_grouping   postprocess.py:78-169
+ * offsets (D, 2, h, w) fp32 (dy, dx) in full-resolution pixel units; step = 1 or 4.
+ * id = 1 + index of the first centre with the strictly smallest
+ *      d = sqrtf(fmaf(dx, dx, dy*dy)),  dy = step*cy - (step*y + off_y), dx likewise
+ * (the rounding torch.norm performs on the reference's CPU path); when K > 20 a pixel whose
+ * every d >= 1e5 keeps id 0 (chunked path, :97-111).  K = min(count, cap); K == 0 -> ids 0.
+ * out_ids (D, h, w) uint16.                                                                     */
+int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count, int cap,
+                     const float *offsets, int D, int h, int w, int step, uint16_t *out_ids,
+                     void *stream);
+
+/* ---- P4b + P5: instance cells -> panoptic labels -------------------------------------------
+ * replaces get_instance_cells (nearest upsample)   engines.py:257-275
+ *          get_panoptic_seg                        engines.py:277-292, patterns.py:253-277
+ *          merge_semantic_and_instance             postprocess.py:223-296
+ * sem (D, H, W) u8 class ids (< n_classes <= EMP_MAX_CLASSES); ids (D, H/up, W/up) u16 in 0..cap
+ * (nearest-upsampled by `up` on the fly); thing_mask bit c set = class c is a thing.
+ * Per instance id (ascending) with >= 1 thing pixel: class = most frequent class among its thing
+ * pixels (ties -> smallest), new id = per-class counter from 1, pan = class*div + new id.
+ * Non-thing classes: pixels with instance 0 get class*div when their count >= stuff_area.
+ * Everything else = void_label.
+ * work: int32 workspace of emp_fuse_work_elems(D, cap, n_classes) elements (zeroed by the call).
+ * Exactly one of out_pan_u32 / out_pan_i64 (D, H, W) must be non-NULL.                          */
+int64_t emp_fuse_work_elems(int D, int cap, int n_classes);
+int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D, int H, int W, int up,
+                      int cap, int n_classes, uint32_t thing_mask, int64_t label_divisor,
+                      int64_t stuff_area, int64_t void_label, int32_t *work,
+                      uint32_t *out_pan_u32, int64_t *out_pan_i64, void *stream);
+
+/* ---- R1-R3: run extraction + 8-connected components on runs --------------------------------
+ * replaces connected_components                    empanada/inference/rle.py:18-24
+ *          pan_seg_to_rle_seg                      rle.py:26-86
+ *          rle_encode                              empanada/array_utils.py:209-235
+ * Step 1  emp_runs_count: row_counts[d*H+y] = number of maximal constant non-zero spans in row y
+ *         of slice d of pan (D, H, W) u32.
+ * Step 2  emp_exclusive_scan_i32: out[0..n] (n+1 entries) exclusive prefix sum; tmp holds
+ *         emp_scan_tmp_elems(n) int32.
+ * Step 3  emp_runs_extract: SoA run table in raster order, run i of row r sits at
+ *         row_offsets[r] + i: r_start (flat y*W+x0 inside the slice), r_len, r_val.
+ * Step 4  emp_runs_label: union-find over runs.  Classes whose bit is set in cc_mask are split
+ *         into 8-connected components of equal value and renumbered class*div + k, k = 1.. in
+ *         raster order of the component's first pixel, per slice; runs of other classes keep
+ *         their value as label (one instance per distinct value).  Outputs, per run:
+ *         r_comp (int32) = dense component index over the whole stack (ordered by first run),
+ *         and per component: c_slice, c_label (int64), c_area (int64), c_box (4 x int32:
+ *         y0, x0, y1, x1 half-open), c_first (first run).  n_comp_out (device int32[1]).
+ *         work: int32 workspace of emp_runs_label_work_elems(n_runs) elements.               */
+int emp_runs_count(const uint32_t *pan, int D, int H, int W, int32_t *row_counts, void *stream);
+int64_t emp_scan_tmp_elems(int64_t n);
+int emp_exclusive_scan_i32(const int32_t *in, int64_t n, int32_t *out, int32_t *tmp, void *stream);
+int emp_runs_extract(const uint32_t *pan, int D, int H, int W, const int32_t *row_offsets,
+                     int32_t *r_start, int32_t *r_len, uint32_t *r_val, void *stream);
+int64_t emp_runs_label_work_elems(int64_t n_runs);
+int emp_runs_label(const int32_t *r_start, const int32_t *r_len, const uint32_t *r_val,
+                   const int32_t *row_offsets, int64_t n_runs, int D, int H, int W,
+                   int64_t label_divisor, uint32_t cc_mask, int32_t *work, int32_t *r_comp,
+                   int32_t *c_slice, int64_t *c_label, int64_t *c_area, int32_t *c_box,
+                   int32_t *c_first, int32_t *n_comp_out, void *stream);
+
+/* ---- M2: overlaps between components of consecutive slices ---------------------------------
+ * replaces rle_intersection / intersection_from_ranges  array_utils.py:340-403 for the pairs the
+ *          matcher asks for (rle_matcher                 inference/matcher.py:198-210)
+ * For every run of slice d and every run of slice d+1 in the same row whose x-spans overlap and
+ * whose labels are of the same class, appends (comp_a, comp_b, overlap) to out_triplets
+ * (cap_triplets x 3 int32, unordered; duplicates of a pair must be summed by the caller).
+ * n_out (device int32[1]) counts all triplets found (may exceed the capacity -> error).        */
+int emp_runs_overlap_next(const int32_t *r_start, const int32_t *r_len, const int32_t *r_comp,
+                          const int64_t *c_label, const int32_t *row_offsets, int64_t n_runs, int D,
+                          int H, int W, int64_t label_divisor, int32_t *out_triplets,
+                          int64_t cap_triplets, int32_t *n_out, void *stream);
+
+/* ---- M2/C1: intersection of arbitrary RLE pairs --------------------------------------------
+ * replaces rle_intersection                        array_utils.py:371-403 (the exact sweep of
+ *          intersection_from_ranges :340-369, also for malformed / overlapping runs), as used by
+ *          rle_iou :405-429 in object_iou_graph    empanada/consensus.py:276-285
+ * Instance i owns runs [inst_off[i], inst_off[i+1]) of (starts, lens) int64; each instance's runs
+ * must already be STABLY sorted by start (emp_sort_u64_i32 with key = instance<<40 | start does
+ * it).  pairs (n_pairs, 2) int32 instance indices (a, b); out_inter (n_pairs) int64.            */
+int emp_rle_pair_intersections(const int64_t *starts, const int64_t *lens, const int64_t *inst_off,
+                               const int32_t *pairs, int64_t n_pairs, int64_t *out_inter,
+                               void *stream);
+
+/* ---- stable key/value radix sort (rocPRIM via hipCUB), used to order run tables --------------
+ * keys 64-bit unsigned, values int32; bits [begin_bit, end_bit) are compared.
+ * work: emp_sort_work_bytes(n) bytes.                                                          */
+int64_t emp_sort_work_bytes(int64_t n);
+int emp_sort_u64_i32(const uint64_t *keys_in, uint64_t *keys_out, const int32_t *vals_in,
+                     int32_t *vals_out, int64_t n, int begin_bit, int end_bit, void *work,
+                     int64_t work_bytes, void *stream);
+
+/* ---- C3: range voting / joining -------------------------------------------------------------
+ * replaces vote_by_ranges / rle_voting / split_range_by_votes / extend_range / join_ranges
+ *          empanada/array_utils.py:457-671
+ * n ranges [starts[i], ends[i]) int64 (< 2^40), each tagged with a group id grp[i] in
+ * [0, n_groups), in any order.  For each group emits, ascending, the maximal ranges covered by
+ * at least vote_thr of its input ranges (vote_thr == 1: the union; touching ranges merge -- the
+ * reference's sweeps reduce to exactly this coverage count).
+ * out_ranges (n, 2) int64 receives all groups back to back; group g owns rows
+ * [out_off[g], out_off[g+1]) (out_off: n_groups+1 int32).
+ * work: emp_vote_work_bytes(n) bytes.                                                          */
+int64_t emp_vote_work_bytes(int64_t n);
+int emp_vote_ranges(const int64_t *starts, const int64_t *ends, const int32_t *grp, int64_t n,
+                    int n_groups, int vote_thr, void *work, int64_t work_bytes,
+                    int64_t *out_ranges, int32_t *out_off, void *stream);
+
+/* ---- R4 / Z1: paint runs into a label volume ------------------------------------------------
+ * replaces numpy_fill_instances                    array_utils.py:725-737
+ *          fill_func / zarr_fill_instances         empanada/zarr_utils.py:49-58,88-175
+ * Runs (starts, lens int64 into the flat volume) carry an order index (position of their
+ * instance in dict order) and ids[order] is painted; where runs of different instances overlap
+ * the later instance wins, as in the reference's sequential fill.  Ids must be < 2^31.          */
+int emp_fill_runs_u32(uint32_t *vol, int64_t n_vox, const int64_t *starts, const int64_t *lens,
+                      const int32_t *order, int64_t n_runs, const uint32_t *ids, void *stream);
+int emp_fill_runs_u8(uint8_t *vol, int64_t n_vox, const int64_t *starts, const int64_t *lens,
+                     int64_t n_runs, uint8_t value, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMP_HIP_H */

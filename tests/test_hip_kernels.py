@@ -1,0 +1,334 @@
+"""GPU: each HIP kernel group against the oracle (bit-exact) on seeded inputs and against the
+fixtures produced by the reference (tests/golden)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_instances_equal, load_golden, unpack_rle_seg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from empanada_amd import _hip
+    _hip.load()
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return _hip
+
+
+def _oracle_median_stack(x, ks, thr):
+    """oracle/postprocess.MedianQueue over a (D,C,H,W) stack -> filtered probs, emitted order."""
+    from oracle import postprocess as OP
+    q = OP.MedianQueue(ks)
+    outs = []
+    for t in range(len(x)):
+        q.enqueue({'sem': x[t:t + 1].copy()})
+        o = q.get_next(['sem'])
+        if o is not None:
+            outs.append(o['sem'].copy())
+    outs += [o['sem'].copy() for o in q.end()]
+    filt = np.concatenate(outs, axis=0)
+    sem = np.concatenate([OP.harden_seg(f[None], thr)[0] for f in filt], axis=0)
+    return filt, sem
+
+
+@pytest.mark.parametrize('ks', [1, 3, 5, 7, 9, 11])
+@pytest.mark.parametrize('C', [1, 3])
+def test_median_harden_stack(hip, ks, C):
+    rng = np.random.default_rng(ks * 10 + C)
+    D, H, W = max(ks, 13), 24, 40
+    x = rng.random((D, C, H, W), dtype=np.float32)
+    x[:, :, 0, :8] = 0.5        # exact ties with the threshold / between channels
+    filt, sem = _oracle_median_stack(x, ks, 0.5)
+    gsem, gfilt = hip.median_harden_stack(torch.from_numpy(x).cuda(), ks, 0.5, want_prob=True)
+    np.testing.assert_array_equal(gfilt.cpu().numpy(), filt)
+    np.testing.assert_array_equal(gsem.cpu().numpy(), sem.astype(np.uint8))
+
+
+def test_median_golden(hip):
+    g = load_golden('median_queue')
+    for i in range(int(g['n'])):
+        xs, ks = g[f'q{i}_x'], int(g[f'q{i}_ks'])
+        if len(xs) < ks:
+            continue        # short stacks are degraded on the host (engine tests)
+        x = xs[:, 0]        # (n, C=2... stored as (n,1,2,6,7)) -> (n,2,6,7)
+        _, filt = hip.median_harden_stack(torch.from_numpy(x).cuda(), ks, 0.5, want_prob=True)
+        np.testing.assert_array_equal(filt.cpu().numpy(), g[f'q{i}_out'][:, 0])
+
+
+@pytest.mark.parametrize('ks', [3, 7, 11])
+def test_median_step(hip, ks):
+    rng = np.random.default_rng(ks)
+    xs = [rng.random((1, 2, 33, 17), dtype=np.float32) for _ in range(ks)]
+    exp = np.sort(np.stack(xs), axis=0)[ks // 2]
+    got = hip.median_step([torch.from_numpy(x).cuda() for x in xs])
+    np.testing.assert_array_equal(got.cpu().numpy(), exp)
+
+
+def test_find_centers_golden_and_random(hip):
+    from oracle import postprocess as OP
+    g = load_golden('find_centers')
+    cases = [(g[f'c{i}_hmp'], float(g[f'c{i}_par'][0]), int(g[f'c{i}_par'][1]), g[f'c{i}_ctr'])
+             for i in range(int(g['n']))]
+    rng = np.random.default_rng(5)
+    for (h, w, k) in [(130, 257, 7), (64, 64, 3), (16, 300, 5), (200, 70, 8), (65, 129, 2)]:
+        hm = (rng.random((h, w), dtype=np.float32) ** 8).astype(np.float32)
+        hm[3:6, 10:14] = 0.7
+        cases.append((hm, 0.1, k, OP.find_instance_center(hm[None, None], 0.1, k)))
+    for hm, thr, k, exp in cases:
+        idx, cnt = hip.find_centers(torch.from_numpy(hm[None]).cuda(), thr, k, cap=4096)
+        n = int(cnt[0])
+        assert n == len(exp)
+        flat = idx[0, :n].cpu().numpy()
+        got = np.stack([flat // hm.shape[1], flat % hm.shape[1]], axis=1)
+        np.testing.assert_array_equal(got, exp)
+
+
+def test_find_centers_batched_matches_single(hip):
+    rng = np.random.default_rng(6)
+    hm = (rng.random((5, 96, 80), dtype=np.float32) ** 6).astype(np.float32)
+    hm[2] = 0            # a slice without centres
+    idx, cnt = hip.find_centers(torch.from_numpy(hm).cuda(), 0.1, 7, cap=512)
+    from oracle import postprocess as OP
+    for d in range(5):
+        exp = OP.find_instance_center(hm[d][None, None], 0.1, 7)
+        assert int(cnt[d]) == len(exp)
+        flat = idx[d, :len(exp)].cpu().numpy()
+        np.testing.assert_array_equal(np.stack([flat // 80, flat % 80], 1).reshape(-1, 2), exp)
+
+
+def _group(hip, ctr, off, step):
+    h, w = off.shape[-2:]
+    K = len(ctr)
+    cap = max(K, 1)
+    idx = torch.zeros((1, cap), dtype=torch.int32)
+    idx[0, :K] = torch.from_numpy((ctr[:, 0] * w + ctr[:, 1]).astype(np.int32))
+    cnt = torch.tensor([K], dtype=torch.int32)
+    ids = hip.group_pixels(idx.cuda(), cnt.cuda(), torch.from_numpy(off).cuda(), step)
+    return ids.cpu().numpy().astype(np.int64)
+
+
+def test_group_pixels_golden(hip):
+    g = load_golden('group_pixels')
+    for i in range(int(g['n'])):
+        got = _group(hip, g[f'g{i}_ctr'], g[f'g{i}_off'], int(g[f'g{i}_step']))
+        np.testing.assert_array_equal(got, g[f'g{i}_ids'], err_msg=f'case {i}')
+
+
+@pytest.mark.parametrize('K,step', [(1, 1), (20, 1), (21, 1), (333, 1), (64, 4), (7, 4)])
+def test_group_pixels_vs_oracle(hip, K, step):
+    from oracle import postprocess as OP
+    rng = np.random.default_rng(K * 7 + step)
+    h, w = 96, 160
+    ctr = np.stack([rng.integers(0, h, K), rng.integers(0, w, K)], axis=1).astype(np.int64)
+    # integer offsets produce many exact distance ties; the fractional part produces near ties
+    off = rng.integers(-12, 13, (1, 2, h, w)).astype(np.float32) * step
+    off[0, :, : h // 2] += rng.normal(0, 1e-3, (2, h // 2, w)).astype(np.float32)
+    np.testing.assert_array_equal(_group(hip, ctr, off, step), OP.group_pixels(ctr, off, step=step))
+
+
+def test_fuse_golden_and_random(hip):
+    from oracle import postprocess as OP
+    g = load_golden('merge_sem_ins')
+    cases = []
+    for i in range(int(g['n'])):
+        div, stuff, void = (int(x) for x in g[f'm{i}_par'])
+        cases.append((g[f'm{i}_sem'][0], g[f'm{i}_ins'][0], [int(t) for t in g[f'm{i}_thing']], div, stuff, void,
+                      g[f'm{i}_pan'][0]))
+    rng = np.random.default_rng(9)
+    for (thing, nc, K) in [([1], 2, 30), ([1, 2, 4], 5, 200), ([2], 3, 3)]:
+        H, W = 64, 96
+        sem = np.repeat(np.repeat(rng.integers(0, nc, (H // 4, W // 8)), 4, 0), 8, 1).astype(np.int64)
+        ids = np.repeat(np.repeat(rng.integers(0, K + 1, (H // 8, W // 4)), 8, 0), 4, 1).astype(np.int64)
+        ins = ids * np.isin(sem, thing)
+        exp = OP.merge_semantic_and_instance(sem[None], ins[None], 1000, thing, 40, 0)[0]
+        cases.append((sem, ids, thing, 1000, 40, 0, exp))
+    for sem, ids, thing, div, stuff, void, exp in cases:
+        K = int(ids.max())
+        nc = int(sem.max()) + 1
+        for dt in (torch.uint32, torch.int64):
+            pan = hip.fuse_panoptic(torch.from_numpy(sem.astype(np.uint8))[None].cuda(),
+                                    torch.from_numpy(ids.astype(np.int16))[None].cuda().view(torch.uint16),
+                                    max(K, 1), nc, thing, div, stuff, void, up=1, out_dtype=dt)
+            np.testing.assert_array_equal(pan[0].cpu().numpy().astype(np.int64), exp)
+
+
+def test_fuse_coarse_upsample(hip):
+    from oracle import postprocess as OP
+    rng = np.random.default_rng(10)
+    H, W, up = 64, 128, 4
+    sem = (rng.random((H, W)) < 0.5).astype(np.int64)
+    ids_c = rng.integers(0, 9, (H // up, W // up)).astype(np.int64)
+    cells = np.repeat(np.repeat(ids_c, up, 0), up, 1)
+    exp = OP.get_panoptic_seg(sem[None], cells[None, None].astype(np.float32), 1000, [1], 64, 0)[0]
+    pan = hip.fuse_panoptic(torch.from_numpy(sem.astype(np.uint8))[None].cuda(),
+                            torch.from_numpy(ids_c.astype(np.int16))[None].cuda().view(torch.uint16),
+                            8, 2, [1], 1000, 64, 0, up=up)
+    np.testing.assert_array_equal(pan[0].cpu().numpy().astype(np.int64), exp)
+
+
+def test_scan(hip):
+    rng = np.random.default_rng(11)
+    for n in [1, 7, 2048, 2049, 100003, 3000000]:
+        x = rng.integers(0, 5, n).astype(np.int32)
+        got = hip.exclusive_scan_i32(torch.from_numpy(x).cuda()).cpu().numpy()
+        np.testing.assert_array_equal(got, np.concatenate([[0], np.cumsum(x)]))
+
+
+def test_rle_seg_golden(hip):
+    from empanada_amd.inference import rle
+    g = load_golden('rle_seg')
+    for i in range(int(g['n'])):
+        pan = g[f'r{i}_pan']
+        got = rle.pan_seg_to_rle_seg(pan, [1, 2, 3], 1000, [1, 2], bool(g[f'r{i}_fc']))
+        exp = unpack_rle_seg(g, f'r{i}')
+        for c in (1, 2, 3):
+            assert_instances_equal(got[c], exp.get(c, {}))
+        np.testing.assert_array_equal(rle.rle_seg_to_pan_seg(got, pan.shape), g[f'r{i}_back'])
+
+
+@pytest.mark.parametrize('shape', [(5, 37, 53), (3, 64, 128), (2, 200, 260), (1, 9, 1024)])
+def test_runs_cc_vs_oracle(hip, shape):
+    """stack extraction: components, boxes, areas and merged runs against the oracle, slice by slice."""
+    from empanada_amd.inference import rle
+    from oracle import rle_seg as OS
+    rng = np.random.default_rng(sum(shape))
+    D, H, W = shape
+    base = rng.integers(0, 5, (D, H // 3 + 1, W // 2 + 1))
+    pan = np.repeat(np.repeat(base, 3, 1), 2, 2)[:, :H, :W]
+    noise = rng.random((D, H, W)) < 0.15
+    pan = np.where(noise, rng.integers(0, 5, (D, H, W)), pan)
+    cls = np.repeat(np.repeat(rng.integers(1, 4, (D, H // 8 + 1, W // 8 + 1)), 8, 1), 8, 2)[:, :H, :W]
+    pan = np.where(pan > 0, cls * 1000 + pan, 0).astype(np.int64)
+    pan[:, :, -1] = pan[:, :, 0]            # row-wrapping runs
+    segs, table = rle.stack_to_rle_segs(hip.np_to_dev_u32(pan), [1, 2, 3], 1000, [1, 2], True)
+    for d in range(D):
+        exp = OS.pan_seg_to_rle_seg(pan[d], [1, 2, 3], 1000, [1, 2], True)
+        for c in (1, 2, 3):
+            assert_instances_equal(segs[d][c], exp[c])
+    # areas
+    areas = table.c_area.cpu().numpy()
+    lab = table.c_label.cpu().numpy()
+    sl = table.c_slice.cpu().numpy()
+    for c in range(table.n_comp):
+        inst = segs[int(sl[c])][int(lab[c] // 1000)][int(lab[c])]
+        assert areas[c] == inst['runs'].sum()
+
+
+def test_connected_components_api(hip):
+    from empanada_amd.inference import rle
+    from oracle import rle_seg as OS
+    rng = np.random.default_rng(3)
+    seg = np.repeat(np.repeat(rng.integers(0, 3, (20, 25)), 3, 0), 2, 1).astype(np.int64)
+    np.testing.assert_array_equal(rle.connected_components(seg), OS.connected_components(seg))
+
+
+def test_overlap_next(hip):
+    from empanada_amd.inference import rle
+    rng = np.random.default_rng(12)
+    D, H, W = 6, 48, 64
+    pan = np.repeat(np.repeat(rng.integers(0, 4, (D, H // 4, W // 4)), 4, 1), 4, 2).astype(np.int64)
+    pan = np.where(pan > 0, 1000 + pan, 0)
+    pan[rng.random(pan.shape) < 0.05] = 2000
+    segs, table = rle.stack_to_rle_segs(hip.np_to_dev_u32(pan), [1, 2], 1000, [1], True)
+    trip = hip.overlap_next(table, 1000).cpu().numpy()
+    lab = table.c_label.cpu().numpy()
+    sl = table.c_slice.cpu().numpy()
+    got = {}
+    for a, b, n in trip:
+        got[(int(a), int(b))] = got.get((int(a), int(b)), 0) + int(n)
+    # dense reference: per-pixel pairs of component maps
+    comp_map = np.full((D, H * W), -1, dtype=np.int64)
+    rs, rl, rc = (x.cpu().numpy() for x in (table.r_start, table.r_len, table.r_comp))
+    for s, l, c in zip(rs, rl, rc):
+        comp_map[sl[c], s:s + l] = c
+    exp = {}
+    for d in range(D - 1):
+        a, b = comp_map[d], comp_map[d + 1]
+        m = (a >= 0) & (b >= 0)
+        m &= (lab[np.where(a >= 0, a, 0)] // 1000) == (lab[np.where(b >= 0, b, 0)] // 1000)
+        for x, y in zip(a[m], b[m]):
+            exp[(int(x), int(y))] = exp.get((int(x), int(y)), 0) + 1
+    assert got == exp
+
+
+def test_pair_intersections_and_iou(hip):
+    from empanada_amd import array_utils as AU
+    from oracle import rle_ops as OR
+    g = load_golden('array_utils')
+    for i in range(6):
+        a, b = g[f'u{i}_a'], g[f'u{i}_b']
+        sa, ra = OR.rle_encode(a); sb, rb = OR.rle_encode(b)
+        assert AU.rle_intersection(sa, ra, sb, rb) == int(g[f'u{i}_inter'])
+        assert AU.rle_iou(sa, ra, sb, rb) == float(g[f'u{i}_iou'])
+        assert AU.rle_ioa(sa, ra, sb, rb) == float(g[f'u{i}_ioa'])
+    for i in range(6, 10):      # malformed rles: the literal sweep
+        assert AU.rle_intersection(g[f'u{i}_sa'], g[f'u{i}_ra'], g[f'u{i}_sb'], g[f'u{i}_rb']) == int(g[f'u{i}_inter'])
+    rng = np.random.default_rng(13)
+    insts = []
+    for _ in range(12):
+        s = rng.integers(0, 5000, 60); r = rng.integers(1, 40, 60)
+        insts.append((s, r))
+    pairs = [(i, j) for i in range(12) for j in range(12) if i != j]
+    got = AU.rle_pair_intersections([s for s, _ in insts], [r for _, r in insts], pairs)
+    exp = [OR.rle_intersection(*insts[i], *insts[j]) for i, j in pairs]
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_vote_and_join(hip):
+    from empanada_amd import array_utils as AU
+    from oracle import rle_ops as OR
+    g = load_golden('array_utils')
+    for i in range(6):
+        rngs = []
+        for key in ('a', 'b', 'c'):
+            s, r = OR.rle_encode(g[f'u{i}_{key}'])
+            rngs.append(np.stack([s, s + r], 1))
+        np.testing.assert_array_equal(AU.vote_by_ranges([r.copy() for r in rngs], 2), g[f'u{i}_vote2'])
+        np.testing.assert_array_equal(AU.vote_by_ranges([r.copy() for r in rngs], 3), g[f'u{i}_vote3'])
+        np.testing.assert_array_equal(AU.vote_by_ranges([r.copy() for r in rngs], 1), g[f'u{i}_join'])
+        ms, mr = AU.merge_rles(g[f'u{i}_sa'], g[f'u{i}_ra'], rngs[1][:, 0], rngs[1][:, 1] - rngs[1][:, 0])
+        np.testing.assert_array_equal(ms, g[f'u{i}_ms']); np.testing.assert_array_equal(mr, g[f'u{i}_mr'])
+    # overlapping ranges inside one list (xz wrap bug shape), big offsets, many groups at once
+    rng = np.random.default_rng(14)
+    groups = []
+    for _ in range(40):
+        lst = []
+        for _ in range(rng.integers(1, 5)):
+            s = rng.integers(0, 2 ** 34, 30) ; e = s + rng.integers(1, 2000, 30)
+            lst.append(np.stack([s, e], 1))
+        base = lst[0].copy(); base[:, 1] += 500
+        lst.append(base)
+        groups.append(lst)
+    for thr in (1, 2, 3):
+        got = AU.vote_groups(groups, thr)
+        for gi, lst in enumerate(groups):
+            exp = OR.vote_by_ranges([r.copy() for r in lst], thr) if thr > 1 else OR.join_ranges([r.copy() for r in lst])
+            np.testing.assert_array_equal(got[gi].reshape(-1, 2), np.asarray(exp).reshape(-1, 2))
+    with pytest.raises(UnboundLocalError):
+        AU.join_ranges([np.array([[0, 5]])])
+    np.testing.assert_array_equal(
+        AU.vote_by_ranges([np.array([[0, 5]]), np.array([[5, 9]]), np.array([[3, 6]])], 2), [[3, 6]])
+
+
+def test_fill_overlapping_order(hip):
+    from empanada_amd import array_utils as AU
+    from oracle import rle_ops as OR
+    rng = np.random.default_rng(15)
+    inst = {}
+    for k in [7, 3, 12, 5, 9]:           # dict order is not id order; later entries overwrite
+        s = np.sort(rng.integers(0, 4000, 25)); r = rng.integers(1, 120, 25)
+        inst[k] = {'starts': s, 'runs': r}
+    exp = OR.numpy_fill_instances(np.zeros((10, 20, 25), np.uint32), inst)
+    got = AU.numpy_fill_instances(np.zeros((10, 20, 25), np.uint32), inst)
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_sort(hip):
+    rng = np.random.default_rng(16)
+    k = rng.integers(0, 2 ** 50, 100000).astype(np.uint64)
+    v = np.arange(100000, dtype=np.int32)
+    ko, vo = hip.sort_u64_i32(torch.from_numpy(k.view(np.int64)).cuda().view(torch.uint64), torch.from_numpy(v).cuda())
+    order = np.argsort(k, kind='stable')
+    np.testing.assert_array_equal(vo.cpu().numpy(), v[order])
