@@ -246,7 +246,7 @@ def overlap_next(t, label_divisor):
     while True:
         out = torch.empty((cap, 3), dtype=torch.int32, device=dev)
         n = torch.zeros((1,), dtype=torch.int32, device=dev)
-        call('emp_runs_overlap_next', _ptr(t.r_start), _ptr(t.r_len), _ptr(t.r_comp), _ptr(t.c_label),
+        call('emp_runs_overlap_next', _ptr(t.r_start), _ptr(t.r_len), _ptr(t.r_comp), _ptr(t.r_val),
              _ptr(t.row_offsets), t.n_runs, t.D, t.H, t.W, int(label_divisor), _ptr(out), cap, _ptr(n), stream())
         cnt = int(n.item())
         if cnt <= cap:

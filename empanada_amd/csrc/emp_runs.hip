@@ -471,7 +471,7 @@ extern "C" int emp_runs_label(const int32_t *r_start, const int32_t *r_len, cons
 // overlaps between the runs of slice d and slice d+1 (same row, same class)
 __global__ void overlap_next_kernel(int64_t n, int D, int H, int W, int64_t div,
                                     const int32_t *__restrict__ r_start, const int32_t *__restrict__ r_len,
-                                    const int32_t *__restrict__ r_comp, const int64_t *__restrict__ c_label,
+                                    const int32_t *__restrict__ r_comp, const uint32_t *__restrict__ r_val,
                                     const int32_t *__restrict__ row_offsets, int32_t *__restrict__ out,
                                     int64_t cap, int32_t *__restrict__ n_out)
 {
@@ -488,7 +488,7 @@ __global__ void overlap_next_kernel(int64_t n, int D, int H, int W, int64_t div,
         int64_t rn = r + H;  // same y, next slice
         int a0 = r_start[i] % W, a1 = a0 + r_len[i];
         int ca = r_comp[i];
-        int64_t cls = c_label[ca] / div;
+        int64_t cls = (int64_t)r_val[i] / div;  // class of the ORIGINAL value (labels may overflow div)
         int l = row_offsets[rn], h = row_offsets[rn + 1];
         int jl = l, jh = h;
         while (jl < jh) {  // first run with b1 > a0
@@ -501,7 +501,7 @@ __global__ void overlap_next_kernel(int64_t n, int D, int H, int W, int64_t div,
             if (b0 >= a1) break;
             int b1 = b0 + r_len[j];
             int cb = r_comp[j];
-            if (c_label[cb] / div != cls) continue;
+            if ((int64_t)r_val[j] / div != cls) continue;
             int ov = min(a1, b1) - max(a0, b0);
             int slot = atomicAdd(n_out, 1);
             if (slot < cap) {
@@ -514,7 +514,7 @@ __global__ void overlap_next_kernel(int64_t n, int D, int H, int W, int64_t div,
 }
 
 extern "C" int emp_runs_overlap_next(const int32_t *r_start, const int32_t *r_len, const int32_t *r_comp,
-                                     const int64_t *c_label, const int32_t *row_offsets, int64_t n_runs, int D,
+                                     const uint32_t *r_val, const int32_t *row_offsets, int64_t n_runs, int D,
                                      int H, int W, int64_t label_divisor, int32_t *out_triplets,
                                      int64_t cap_triplets, int32_t *n_out, void *stream)
 {
@@ -524,11 +524,11 @@ extern "C" int emp_runs_overlap_next(const int32_t *r_start, const int32_t *r_le
     hipStream_t st = emp_stream(stream);
     if (hipMemsetAsync(n_out, 0, sizeof(int32_t), st) != hipSuccess) EMP_FAIL(EMP_ELAUNCH, "overlap_next: memset");
     if (n_runs == 0 || D < 2) return EMP_OK;
-    EMP_REQUIRE(r_start && r_len && r_comp && c_label && (out_triplets || cap_triplets == 0),
+    EMP_REQUIRE(r_start && r_len && r_comp && r_val && (out_triplets || cap_triplets == 0),
                 "overlap_next: null pointer");
     int grid = emp_grid(n_runs, 256, 4096);
     hipLaunchKernelGGL(overlap_next_kernel, dim3(grid), dim3(256), 0, st, n_runs, D, H, W, label_divisor, r_start,
-                       r_len, r_comp, c_label, row_offsets, out_triplets, cap_triplets, n_out);
+                       r_len, r_comp, r_val, row_offsets, out_triplets, cap_triplets, n_out);
     EMP_CHECK_LAUNCH("emp_runs_overlap_next");
     return EMP_OK;
 }

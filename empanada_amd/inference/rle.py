@@ -67,10 +67,12 @@ def stack_to_rle_segs(pan, labels, label_divisor, thing_list, force_connected=Tr
     c_slice = table.c_slice.cpu().numpy()
     c_label = table.c_label.cpu().numpy()
     c_box = table.c_box.cpu().numpy()
+    # the class of a component is that of its ORIGINAL value: relabelled ids may run past the divisor
+    c_val = table.r_val.cpu().numpy()[table.c_first.cpu().numpy()] if table.n_comp else np.zeros(0, np.uint32)
     starts, runs, off = runs_to_instances(r_start, r_len, r_comp, table.n_comp)
     segs = [{l: {} for l in labels} for _ in range(D)]
     if table.n_comp:
-        cls = c_label // label_divisor
+        cls = c_val.astype(np.int64) // label_divisor
         # instances of one class come out in ascending label order (regionprops order, rle.py:75)
         for c in np.lexsort((c_label, cls, c_slice)):
             k = int(cls[c])

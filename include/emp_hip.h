@@ -137,11 +137,11 @@ int emp_runs_label(const int32_t *r_start, const int32_t *r_len, const uint32_t 
  * replaces rle_intersection / intersection_from_ranges  array_utils.py:340-403 for the pairs the
  *          matcher asks for (rle_matcher                 inference/matcher.py:198-210)
  * For every run of slice d and every run of slice d+1 in the same row whose x-spans overlap and
- * whose labels are of the same class, appends (comp_a, comp_b, overlap) to out_triplets
+ * whose values r_val are of the same class (value / label_divisor), appends (comp_a, comp_b, overlap) to out_triplets
  * (cap_triplets x 3 int32, unordered; duplicates of a pair must be summed by the caller).
  * n_out (device int32[1]) counts all triplets found (may exceed the capacity -> error).        */
 int emp_runs_overlap_next(const int32_t *r_start, const int32_t *r_len, const int32_t *r_comp,
-                          const int64_t *c_label, const int32_t *row_offsets, int64_t n_runs, int D,
+                          const uint32_t *r_val, const int32_t *row_offsets, int64_t n_runs, int D,
                           int H, int W, int64_t label_divisor, int32_t *out_triplets,
                           int64_t cap_triplets, int32_t *n_out, void *stream);
 

@@ -211,8 +211,9 @@ def test_runs_cc_vs_oracle(hip, shape):
     areas = table.c_area.cpu().numpy()
     lab = table.c_label.cpu().numpy()
     sl = table.c_slice.cpu().numpy()
+    val = table.r_val.cpu().numpy()[table.c_first.cpu().numpy()]
     for c in range(table.n_comp):
-        inst = segs[int(sl[c])][int(lab[c] // 1000)][int(lab[c])]
+        inst = segs[int(sl[c])][int(val[c] // 1000)][int(lab[c])]
         assert areas[c] == inst['runs'].sum()
 
 
