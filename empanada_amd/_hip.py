@@ -47,6 +47,7 @@ SIGNATURES = {
     'emp_runs_label_work_elems': (_L, [_L]),
     'emp_runs_label': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _L, _U32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'emp_runs_overlap_next': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P, _L, _P, _P]),
+    'emp_box_pairs': (_I, [_P, _L, _P, _L, _I, _P, _P, _I, _P, _L, _P, _P]),
     'emp_rle_pair_intersections': (_I, [_P, _P, _P, _P, _L, _P, _P]),
     'emp_sort_work_bytes': (_L, [_L]),
     'emp_sort_u64_i32': (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
@@ -298,3 +299,24 @@ def fill_runs_u8(vol, starts, lens, value):
     require_gpu()
     call('emp_fill_runs_u8', _ptr(vol), vol.numel(), _ptr(starts), _ptr(lens), starts.numel(), int(value), stream())
     return vol
+
+
+def box_pairs(boxes_a, boxes_b=None, src_a=None, src_b=None, upper_only=False):
+    """boxes (n, 2*nd) int32 cuda -> (k, 2) int32 pairs with positive intersection (arbitrary order)."""
+    require_gpu()
+    self_pairs = boxes_b is None
+    if self_pairs:
+        boxes_b, src_b = boxes_a, src_a
+    na, nb = boxes_a.shape[0], boxes_b.shape[0]
+    nd = boxes_a.shape[1] // 2
+    dev = boxes_a.device
+    cap = max(16 * (na + nb), 4096)
+    while True:
+        out = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        n = torch.zeros((1,), dtype=torch.int32, device=dev)
+        call('emp_box_pairs', _ptr(boxes_a.contiguous()), na, _ptr(boxes_b.contiguous()), nb, nd, _ptr(src_a),
+             _ptr(src_b), int(bool(upper_only)), _ptr(out), cap, _ptr(n), stream())
+        cnt = int(n.item())
+        if cnt <= cap:
+            return out[:cnt]
+        cap = cnt

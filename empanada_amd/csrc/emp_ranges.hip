@@ -302,3 +302,50 @@ extern "C" int emp_fill_runs_u8(uint8_t *vol, int64_t n_vox, const int64_t *star
     EMP_CHECK_LAUNCH("emp_fill_runs_u8");
     return EMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// M1: all pairs of boxes with strictly positive intersection (array_utils.py:144-172).
+// One thread per (a, b) pair; boxes are tiny and stay in L1/L2.  Output order is arbitrary.
+__global__ __launch_bounds__(256) void box_pairs_kernel(const int32_t *__restrict__ ba, int64_t na,
+                                                        const int32_t *__restrict__ bb, int64_t nb, int nd,
+                                                        const int32_t *__restrict__ src_a,
+                                                        const int32_t *__restrict__ src_b, int upper_only,
+                                                        int32_t *__restrict__ out, int64_t cap,
+                                                        int32_t *__restrict__ n_out)
+{
+    const int64_t nbx = (nb + blockDim.x - 1) / blockDim.x;
+    const int64_t i = blockIdx.x / nbx;
+    const int64_t j = (int64_t)(blockIdx.x % nbx) * blockDim.x + threadIdx.x;
+    if (j >= nb) return;
+    if (upper_only && j <= i) return;
+    if (src_a && src_b && src_a[i] == src_b[j]) return;
+    const int32_t *a = ba + i * 2 * nd, *b = bb + j * 2 * nd;
+    bool hit = true;
+    for (int k = 0; k < nd; ++k) {
+        int lo = max(a[k], b[k]), hi = min(a[k + nd], b[k + nd]);
+        hit = hit && (hi - lo > 0);
+    }
+    if (hit) {
+        int slot = atomicAdd(n_out, 1);
+        if (slot < cap) { out[2 * (int64_t)slot] = (int32_t)i; out[2 * (int64_t)slot + 1] = (int32_t)j; }
+    }
+}
+
+extern "C" int emp_box_pairs(const int32_t *boxes_a, int64_t na, const int32_t *boxes_b, int64_t nb, int ndim,
+                             const int32_t *src_a, const int32_t *src_b, int upper_only, int32_t *out_pairs,
+                             int64_t cap, int32_t *n_out, void *stream)
+{
+    EMP_REQUIRE(n_out, "box_pairs: null n_out");
+    EMP_REQUIRE(ndim == 2 || ndim == 3, "box_pairs: ndim must be 2 or 3");
+    EMP_REQUIRE(na >= 0 && nb >= 0 && cap >= 0, "box_pairs: bad sizes");
+    hipStream_t st = emp_stream(stream);
+    if (hipMemsetAsync(n_out, 0, sizeof(int32_t), st) != hipSuccess) EMP_FAIL(EMP_ELAUNCH, "box_pairs: memset");
+    if (na == 0 || nb == 0) return EMP_OK;
+    EMP_REQUIRE(boxes_a && boxes_b && (out_pairs || cap == 0), "box_pairs: null pointer");
+    int64_t blocks = na * emp_cdiv(nb, 256);
+    EMP_REQUIRE(blocks < (1LL << 31), "box_pairs: too many boxes (%lld x %lld)", (long long)na, (long long)nb);
+    hipLaunchKernelGGL(box_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, boxes_a, na, boxes_b, nb, ndim,
+                       src_a, src_b, upper_only, out_pairs, cap, n_out);
+    EMP_CHECK_LAUNCH("emp_box_pairs");
+    return EMP_OK;
+}

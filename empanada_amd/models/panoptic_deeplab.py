@@ -1,0 +1,288 @@
+"""Panoptic-DeepLab with a ResNet encoder.
+
+State-dict compatible re-implementation of the reference model family (cited per class):
+  encoder   ResNet, 1-channel stem, dilated layer4 for output stride 16   empanada/models/encoders/resnet.py:143-232
+  ASPP                                                                    empanada/models/decoders/aspp.py:22-102
+  decoder   project low-level features, bilinear(align_corners) up, 5x5 separable fuse
+                                                                          empanada/models/decoders/panoptic_deeplab.py:23-80
+  heads     5x5 separable conv + BN + ReLU -> 1x1 conv                    empanada/models/heads.py:9-19
+  model     PanopticDeepLab.forward -> {'sem_logits','ctr_hmp','offsets'} empanada/models/panoptic_deeplab.py:20-115
+The module attribute names reproduce the reference's parameter names (e.g.
+``semantic_decoder.fuse.0.0.sepconv.1.weight``); nothing else is shared with it.
+"""
+import zlib
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+__all__ = ['PanopticDeepLab', 'resnet_encoder', 'prepare_for_inference', 'synthesize_weights']
+
+_RESNETS = {
+    'resnet18': ('basic', [2, 2, 2, 2]), 'resnet34': ('basic', [3, 4, 6, 3]),
+    'resnet50': ('bottleneck', [3, 4, 6, 3]), 'resnet101': ('bottleneck', [3, 4, 23, 3]),
+    'resnet152': ('bottleneck', [3, 8, 36, 3]),
+}
+
+
+def _conv_bn_act(nin, nout, k, stride=1, groups=1, act=True):
+    layers = [nn.Conv2d(nin, nout, k, stride=stride, padding=(k - 1) // 2, groups=groups, bias=False),
+              nn.BatchNorm2d(nout)]
+    if act:
+        layers.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*layers)
+
+
+class SeparableConv2d(nn.Module):
+    """depthwise k x k + pointwise 1 x 1 (blocks.py:15-35); parameters live under `.sepconv.{0,1}`"""
+
+    def __init__(self, nin, nout, kernel_size=3, stride=1, bias=True):
+        super().__init__()
+        self.sepconv = nn.Sequential(
+            nn.Conv2d(nin, nin, kernel_size, stride=stride, padding=(kernel_size - 1) // 2, groups=nin, bias=bias),
+            nn.Conv2d(nin, nout, 1, stride=1, bias=bias))
+
+    def forward(self, x):
+        return self.sepconv(x)
+
+
+def _sepconv_bn_act(nin, nout, k):
+    return nn.Sequential(SeparableConv2d(nin, nout, k, 1, bias=False), nn.BatchNorm2d(nout), nn.ReLU(inplace=True))
+
+
+class _Basic(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class _Bottleneck(nn.Module):
+    """ResNet v1.5 bottleneck: stride on the 3x3 (resnet.py:89-130)"""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class _Cfg:
+    def __init__(self):
+        self.widths = []
+        self.w_stem = 64
+
+
+class ResNetEncoder(nn.Module):
+    """returns [p1 (1/4, stem), p2 (1/4), p3 (1/8), p4 (1/16), p5 (1/16 dilated | 1/32)] (resnet.py:217-229)"""
+
+    def __init__(self, kind, layers, in_channels=1, output_stride=32):
+        super().__init__()
+        assert output_stride in (16, 32)
+        block = _Basic if kind == 'basic' else _Bottleneck
+        self.cfg = _Cfg()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._layer(block, 64, layers[0])
+        self.layer2 = self._layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._layer(block, 256, layers[2], stride=2)
+        last_stride, dil = (1, 2) if output_stride == 16 else (2, 1)
+        self.layer4 = self._layer(block, 512, layers[3], stride=last_stride, dilation=dil)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def _layer(self, block, planes, blocks, stride=1, dilation=1):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                 nn.BatchNorm2d(planes * block.expansion))
+        mods = [block(self.inplanes, planes, stride, down, dilation)]
+        self.inplanes = planes * block.expansion
+        self.cfg.widths.append(self.inplanes)
+        mods += [block(self.inplanes, planes, dilation=dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    def forward(self, x):
+        p1 = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        p2 = self.layer1(p1)
+        p3 = self.layer2(p2)
+        p4 = self.layer3(p3)
+        p5 = self.layer4(p4)
+        return [p1, p2, p3, p4, p5]
+
+
+def resnet_encoder(name, output_stride=32, in_channels=1):
+    kind, layers = _RESNETS[name]
+    return ResNetEncoder(kind, layers, in_channels, output_stride)
+
+
+class _ASPPPooling(nn.Module):
+    def __init__(self, nin, nout):
+        super().__init__()
+        self.aspp_pooling = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(nin, nout, 1, bias=False), nn.ReLU())
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        return F.interpolate(self.aspp_pooling(x), size=size, mode='bilinear', align_corners=True)
+
+
+class ASPP(nn.Module):
+    """1x1 + three dilated 3x3 + image pooling -> concat -> 1x1 project (aspp.py:51-102)"""
+
+    def __init__(self, nin, nout, atrous_rates=(2, 4, 6), dropout_p=0.5):
+        super().__init__()
+        mods = [nn.Sequential(nn.Conv2d(nin, nout, 1, bias=False), nn.BatchNorm2d(nout), nn.ReLU())]
+        for r in atrous_rates:
+            mods.append(nn.Sequential(nn.Conv2d(nin, nout, 3, padding=r, dilation=r, bias=False),
+                                      nn.BatchNorm2d(nout), nn.ReLU()))
+        mods.append(_ASPPPooling(nin, nout))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(nn.Conv2d(5 * nout, nout, 1, bias=False), nn.BatchNorm2d(nout), nn.ReLU(),
+                                     nn.Dropout(dropout_p))
+
+    def forward(self, x):
+        return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
+
+
+class PanopticDeepLabDecoder(nn.Module):
+    """decoders/panoptic_deeplab.py:23-80"""
+
+    def __init__(self, in_channels, decoder_channels, low_level_stages, low_level_channels,
+                 low_level_channels_project, atrous_rates, aspp_channels=None, aspp_dropout=0.5):
+        super().__init__()
+        aspp_channels = aspp_channels or decoder_channels
+        self.aspp = ASPP(in_channels, aspp_channels, atrous_rates, aspp_dropout)
+        self.low_level_stages = list(low_level_stages)
+        project, fuse = [], []
+        for i, (lc, pc) in enumerate(zip(low_level_channels, low_level_channels_project)):
+            project.append(_conv_bn_act(lc, pc, 1))
+            fuse.append(_sepconv_bn_act((aspp_channels if i == 0 else decoder_channels) + pc, decoder_channels, 5))
+        self.project = nn.ModuleList(project)
+        self.fuse = nn.ModuleList(fuse)
+
+    def forward(self, pyramid: List[torch.Tensor]):
+        x = self.aspp(pyramid[-1])
+        for stage, proj, fuse in zip(self.low_level_stages, self.project, self.fuse):
+            low = proj(pyramid[stage])
+            x = F.interpolate(x, size=low.shape[2:], mode='bilinear', align_corners=True)
+            x = fuse(torch.cat((x, low), dim=1))
+        return x
+
+
+class PanopticDeepLabHead(nn.Module):
+    """heads.py:9-19"""
+
+    def __init__(self, nin, n_classes):
+        super().__init__()
+        self.head = nn.Sequential(_sepconv_bn_act(nin, nin, 5), nn.Conv2d(nin, n_classes, 1, bias=True))
+
+    def forward(self, x):
+        return self.head(x)
+
+
+class PanopticDeepLab(nn.Module):
+    """models/panoptic_deeplab.py:20-115.  forward(x (N,1,H,W)) -> dict of full-resolution heads."""
+
+    def __init__(self, encoder='resnet50', num_classes=1, stage4_stride=16, decoder_channels=256,
+                 low_level_stages=(3, 2, 1), low_level_channels_project=(128, 64, 32), atrous_rates=(2, 4, 6),
+                 aspp_channels=None, aspp_dropout=0.1, ins_decoder=False, ins_ratio=0.5, **kwargs):
+        super().__init__()
+        assert encoder in _RESNETS, f'Invalid encoder name {encoder}, choices are {sorted(_RESNETS)}'
+        assert stage4_stride in (16, 32) and min(low_level_stages) > 0
+        self.decoder_channels = decoder_channels
+        self.num_classes = num_classes
+        self.encoder = resnet_encoder(encoder, output_stride=stage4_stride)
+        sem_p, ins_p = (aspp_dropout, aspp_dropout) if isinstance(aspp_dropout, float) else aspp_dropout
+        widths = self.encoder.cfg.widths
+        low_ch = [int(widths[i - 1]) for i in low_level_stages]
+        self.semantic_decoder = PanopticDeepLabDecoder(int(widths[-1]), decoder_channels, low_level_stages, low_ch,
+                                                       list(low_level_channels_project), atrous_rates,
+                                                       aspp_channels, sem_p)
+        if ins_decoder:
+            self.instance_decoder = PanopticDeepLabDecoder(
+                int(widths[-1]), decoder_channels, low_level_stages, low_ch,
+                [int(s * ins_ratio) for s in low_level_channels_project], atrous_rates, aspp_channels, ins_p)
+        else:
+            self.instance_decoder = None
+        self.semantic_head = PanopticDeepLabHead(decoder_channels, num_classes)
+        self.ins_center = PanopticDeepLabHead(decoder_channels, 1)
+        self.ins_xy = PanopticDeepLabHead(decoder_channels, 2)
+
+    @staticmethod
+    def _up4(x):
+        return F.interpolate(x, scale_factor=4.0, mode='bilinear', align_corners=True)
+
+    def forward(self, x):
+        pyramid = self.encoder(x)
+        sem_x = self.semantic_decoder(pyramid)
+        ins_x = sem_x if self.instance_decoder is None else self.instance_decoder(pyramid)
+        return {'sem_logits': self._up4(self.semantic_head(sem_x)),
+                'ctr_hmp': self._up4(self.ins_center(ins_x)),
+                'offsets': self._up4(self.ins_xy(ins_x))}
+
+
+# ----------------------------------------------------------------------------- deployment helpers
+def synthesize_weights(model, scale_bn=True):
+    """Deterministic synthetic weights (no trained checkpoints exist offline):
+    per state-dict key, generator seeded with crc32(key); He-normal convs, BN gamma 1 +- 0.1,
+    small beta / running_mean, running_var 1 + 0.1 * U[0,1)."""
+    sd = model.state_dict()
+    out = {}
+    for key, t in sd.items():
+        g = torch.Generator().manual_seed(zlib.crc32(key.encode()))
+        if key.endswith('num_batches_tracked'):
+            out[key] = torch.zeros_like(t)
+        elif key.endswith('running_var'):
+            out[key] = 1 + 0.1 * torch.rand(t.shape, generator=g)
+        elif key.endswith('running_mean'):
+            out[key] = 0.1 * torch.randn(t.shape, generator=g)
+        elif t.dim() == 4:
+            fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+            out[key] = torch.randn(t.shape, generator=g) * (2.0 / fan_in) ** 0.5
+        elif key.endswith('weight'):
+            out[key] = 1 + 0.1 * torch.randn(t.shape, generator=g)
+        else:
+            out[key] = 0.05 * torch.randn(t.shape, generator=g)
+    model.load_state_dict(out, strict=True)
+    return model
+
+
+def prepare_for_inference(model, device='cuda', dtype=torch.float32, channels_last=True):
+    """eval(), move to the GPU, NHWC memory format (MIOpen's fast layout on gfx950) and optional bf16/fp16
+    weights.  fp32 is the default so that logits stay within the stated tolerance of the CPU reference."""
+    model = model.eval().to(device)
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    if dtype != torch.float32:
+        model = model.to(dtype)
+    return model

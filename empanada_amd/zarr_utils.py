@@ -1,0 +1,107 @@
+"""Volume fill helpers, reference names (``empanada/zarr_utils.py``): ``zarr_fill_instances`` :88-175,
+``chunk_ranges`` :11-47, plus ``zarr_put3d`` / ``zarr_take3d`` which scripts/inference3d_multigpu.py:251,512
+use but the reference never defines.
+
+`zarr` itself is not installed in this image; any array-like with ``shape``, ``chunks``, ``dtype`` and
+slice get/set (a zarr.Array, or a numpy array wrapped by ``ChunkedArray``) is accepted.  The runs are split
+at chunk borders with vectorised integer arithmetic (same ranges as the reference's per-index loop) and each
+chunk is painted on the GPU (emp_fill_runs_u32).
+"""
+import math
+
+import numpy as np
+
+from .array_utils import numpy_fill_instances, put, rle_to_ranges, take
+
+__all__ = ['zarr_fill_instances', 'chunk_ranges', 'zarr_put3d', 'zarr_take3d', 'ChunkedArray']
+
+
+class ChunkedArray:
+    """numpy-backed stand-in with the zarr.Array attributes the fill needs (shape, chunks, nchunks)."""
+
+    def __init__(self, array, chunks):
+        self.array = array
+        self.shape = array.shape
+        self.dtype = array.dtype
+        self.chunks = tuple(s if c is None else c for s, c in zip(array.shape, chunks))
+        self.nchunks = math.prod(math.ceil(s / c) for s, c in zip(self.shape, self.chunks))
+
+    def __getitem__(self, idx):
+        return self.array[idx]
+
+    def __setitem__(self, idx, value):
+        self.array[idx] = value
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.array, dtype=dtype)
+
+
+def chunk_ranges(ranges, modulo, divisor):
+    """zarr_utils.py:11-47 -- split [s,e) ranges wherever chunk(i) = (i % modulo) // divisor changes
+    between consecutive indices i-1, i inside the range.  Returns a list of [s, e] like the reference."""
+    ranges = np.asarray(ranges, dtype=np.int64).reshape(-1, 2)
+    if len(ranges) == 0:
+        return []
+    s_all, e_all = ranges[:, 0], ranges[:, 1]
+    cs = (s_all % modulo) // divisor
+    ce = ((e_all - 1) % modulo) // divisor
+    need = (cs != ce) | ((e_all - s_all) > divisor)
+    out = []
+    for s, e, nd in zip(s_all.tolist(), e_all.tolist(), need.tolist()):
+        if not nd:
+            out.append([s, e])
+            continue
+        cand = []
+        for k in range(s // modulo, (e - 1) // modulo + 1):
+            p0 = k * modulo
+            lo = max(s + 1, p0)
+            j0 = -(-(lo - p0) // divisor)                    # ceil
+            pts = p0 + np.arange(j0, -(-modulo // divisor), dtype=np.int64) * divisor
+            cand.append(pts[(pts > s) & (pts < e) & (pts < p0 + modulo)])
+        cuts = np.unique(np.concatenate(cand)) if cand else np.zeros(0, np.int64)
+        if len(cuts):
+            change = ((cuts % modulo) // divisor) != (((cuts - 1) % modulo) // divisor)
+            cuts = cuts[change]
+        pts = np.concatenate([[s], cuts, [e]])
+        out.extend([[int(a), int(b)] for a, b in zip(pts[:-1], pts[1:])])
+    return out
+
+
+def zarr_fill_instances(array, instances, processes=4):
+    """zarr_utils.py:88-175.  `processes` is accepted for signature compatibility; chunks are painted by the GPU."""
+    d, h, w = array.shape
+    dc, hc, wc = array.chunks
+    for z1 in range(0, d, dc):
+        for y1 in range(0, h, hc):
+            for x1 in range(0, w, wc):
+                z2, y2, x2 = min(d, z1 + dc), min(h, y1 + hc), min(w, x1 + wc)
+                sl = (slice(z1, z2), slice(y1, y2), slice(x1, x2))
+                seg = np.ascontiguousarray(array[sl])
+                cshape = seg.shape
+                sub = {}
+                for instance_id, attrs in instances.items():
+                    rng = rle_to_ranges(np.stack([attrs['starts'], attrs['runs']], axis=1))
+                    rng = np.array(chunk_ranges(rng, d * h * w, dc * h * w)).reshape(-1, 2)
+                    rng = np.array(chunk_ranges(rng, h * w, hc * w)).reshape(-1, 2)
+                    rng = np.array(chunk_ranges(rng, w, wc)).reshape(-1, 2)
+                    if len(rng) == 0:
+                        continue
+                    zs, ys, xs = np.unravel_index(rng[:, 0], array.shape)
+                    keep = (zs >= z1) & (zs < z2) & (ys >= y1) & (ys < y2) & (xs >= x1) & (xs < x2)
+                    if not keep.any():
+                        continue
+                    starts = np.ravel_multi_index((zs[keep] - z1, ys[keep] - y1, xs[keep] - x1), cshape)
+                    sub[instance_id] = {'starts': starts.astype(np.int64),
+                                        'runs': (rng[keep, 1] - rng[keep, 0]).astype(np.int64)}
+                if sub:
+                    array[sl] = numpy_fill_instances(seg, sub).reshape(cshape)
+
+
+def zarr_put3d(stack, index, value, axis):
+    """scripts/inference3d_multigpu.py:251 -- write one slice along `axis` (array_utils.put :25-40)."""
+    put(stack, index, value, axis)
+
+
+def zarr_take3d(stack, index, axis):
+    """scripts/inference3d_multigpu.py:512 -- read one slice along `axis` (array_utils.take :6-23)."""
+    return take(stack, index, axis)

@@ -145,6 +145,18 @@ int emp_runs_overlap_next(const int32_t *r_start, const int32_t *r_len, const in
                           int H, int W, int64_t label_divisor, int32_t *out_triplets,
                           int64_t cap_triplets, int32_t *n_out, void *stream);
 
+/* ---- M1: box screening ------------------------------------------------------------------------
+ * replaces _box_iou / box_iou                     empanada/array_utils.py:144-207 (which pairs exist)
+ *          bounding_box_screening                  empanada/consensus.py:197-231
+ * boxes (n, 2*ndim) int32, half-open (lo..., hi...); ndim 2 or 3.  Emits every (a, b) whose
+ * intersection is strictly positive along every axis; pairs with src_a[a] == src_b[b] are skipped
+ * when both src arrays are given; upper_only != 0 keeps only b > a (self-screening without
+ * duplicates).  out_pairs (cap, 2) int32 in arbitrary order; n_out (device int32[1]) counts all
+ * pairs found (may exceed cap -> caller retries).                                                */
+int emp_box_pairs(const int32_t *boxes_a, int64_t na, const int32_t *boxes_b, int64_t nb, int ndim,
+                  const int32_t *src_a, const int32_t *src_b, int upper_only, int32_t *out_pairs,
+                  int64_t cap, int32_t *n_out, void *stream);
+
 /* ---- M2/C1: intersection of arbitrary RLE pairs --------------------------------------------
  * replaces rle_intersection                        array_utils.py:371-403 (the exact sweep of
  *          intersection_from_ranges :340-369, also for malformed / overlapping runs), as used by

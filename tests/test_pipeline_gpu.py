@@ -1,0 +1,272 @@
+"""GPU: the product package end to end (engines -> RLE -> matching -> trackers -> consensus -> fill),
+through both protocols (per-slice drop-in API and whole-stack fast path), against the fixtures the
+reference produced (tests/golden/engines.npz, pipeline.npz, consensus_kat.npz, matcher_kat.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_instances_equal, load_golden, unpack_instances
+from empanada_amd import synthetic as SY
+
+pytestmark = pytest.mark.gpu
+
+
+class Stub(torch.nn.Module):
+    """hands out pre-computed head tensors slice by slice; 'sem_logits' already holds probabilities"""
+
+    def __init__(self, heads):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+        self.heads, self.t = heads, 0
+
+    def forward(self, x, *a, **k):
+        o = {k2: v[self.t:self.t + 1].clone().to(self.p.device) for k2, v in self.heads.items()}
+        o['sem_logits'] = o.pop('sem')
+        self.t += 1
+        return o
+
+
+@pytest.fixture()
+def prob_passthrough(monkeypatch):
+    from empanada_amd.inference import engines
+    monkeypatch.setattr(engines, 'logits_to_prob', lambda x: x)
+    return engines
+
+
+def _engine_case(g, i):
+    ks, coarse, render, C, nk = (int(x) for x in g[f'e{i}_par'])
+    heads = {'sem': torch.from_numpy(g[f'e{i}_sem']), 'ctr_hmp': torch.from_numpy(g[f'e{i}_ctr']),
+             'offsets': torch.from_numpy(g[f'e{i}_off'])}
+    kw = dict(thing_list=[int(t) for t in g[f'e{i}_thing']], label_divisor=1000, stuff_area=32, void_label=0,
+              nms_threshold=0.1, nms_kernel=nk, confidence_thr=float(g[f'e{i}_thr']), median_kernel_size=ks)
+    return heads, kw, bool(coarse), bool(render), g[f'e{i}_pan']
+
+
+def test_engines_per_slice_protocol(prob_passthrough):
+    EN = prob_passthrough
+    g = load_golden('engines')
+    for i in range(int(g['n'])):
+        heads, kw, coarse, render, exp = _engine_case(g, i)
+        S, _, H, W = heads['sem'].shape
+        stub = Stub(heads).cuda()
+        outs = []
+        if render:
+            eng = EN.PanopticDeepLabRenderEngine3d(stub, padding_factor=16, coarse_boundaries=coarse, **kw)
+            for t in range(S):
+                o = eng(torch.zeros(1, 1, H, W), (H - 3, W - 5))
+                if o is not None:
+                    outs.append(o.cpu().numpy())
+            outs += [o.cpu().numpy() for o in eng.end()]
+        else:
+            eng = EN.PanopticDeepLabEngine3d(stub, **kw)
+            for t in range(S):
+                o = eng(torch.zeros(1, 1, H, W))
+                if o is not None:
+                    outs.append(o.cpu().numpy())
+            outs += [o.cpu().numpy() for o in eng.end()]
+        got = np.stack(outs)
+        assert got.dtype == np.int64
+        np.testing.assert_array_equal(got, exp, err_msg=f'engine case {i}')
+
+
+def test_engines_whole_stack_protocol():
+    from empanada_amd.inference.postprocess import panoptic_stack
+    g = load_golden('engines')
+    for i in range(int(g['n'])):
+        heads, kw, coarse, render, exp = _engine_case(g, i)
+        S, _, H, W = heads['sem'].shape
+        pan, emitted = panoptic_stack(heads['sem'].cuda(), heads['ctr_hmp'].cuda(), heads['offsets'].cuda(),
+                                      coarse_boundaries=coarse if render else False, **kw)
+        assert emitted == list(range(S))
+        got = pan.cpu().numpy().astype(np.int64)
+        exp = exp.reshape(S, *exp.shape[-2:])
+        np.testing.assert_array_equal(got[:, :exp.shape[1], :exp.shape[2]], exp, err_msg=f'engine case {i}')
+
+
+def test_short_stack_loses_the_slices_the_reference_loses():
+    from empanada_amd.inference.postprocess import panoptic_stack
+    from oracle import postprocess as OP
+    lab, cls = SY.planted_labels((4, 48, 48), fill=0.2, rmin=4, rmax=8, seed=3)
+    heads = SY.planted_heads(lab, cls, 'xy', seed=1)
+    kw = dict(thing_list=[1], label_divisor=1000, stuff_area=32, void_label=0, nms_threshold=0.1, nms_kernel=7,
+              confidence_thr=0.5, median_kernel_size=7)
+    pan, emitted = panoptic_stack(heads['sem'].cuda(), heads['ctr_hmp'].cuda(), heads['offsets'].cuda(),
+                                  coarse_boundaries=False, **kw)
+    sem, ctr, off = (heads[k].numpy() for k in ('sem', 'ctr_hmp', 'offsets'))
+    exp = OP.engine3d_stack([sem[t:t + 1] for t in range(4)], [ctr[t:t + 1] for t in range(4)],
+                            [off[t:t + 1] for t in range(4)], coarse_boundaries=False, render=True, **kw)
+    assert emitted == [0, 1, 2]          # ks=7: slices 0..2 raw, slice 3 (the middle slot) is lost
+    np.testing.assert_array_equal(pan.cpu().numpy().astype(np.int64), np.stack(exp)[:, 0])
+
+
+def test_matcher_kat():
+    """reference tests/test_matcher.py:54-66 through the product RLEMatcher"""
+    from empanada_amd.inference import matcher, rle
+    g = load_golden('matcher_kat')
+    m = matcher.RLEMatcher(1, 1000, 0.25, 0.25, True)
+    t = rle.pan_seg_to_rle_seg(g['target'], [1], 1000, [1], False)
+    r = rle.pan_seg_to_rle_seg(g['match'], [1], 1000, [1], False)
+    m.initialize_target(t[1])
+    r[1] = m(r[1], update_target=False)
+    np.testing.assert_array_equal(rle.rle_seg_to_pan_seg(r, (200, 200)), g['out'])
+
+
+def _params(g, i):
+    C, ks, _, head_seed = (int(x) for x in g[f'p{i}_par'])
+    thing = [1] if C == 1 else list(range(1, C))
+    labels = [1] if C == 1 else list(range(1, C + 1))
+    return C, ks, head_seed, thing, labels
+
+
+def test_reference_protocol_matching_and_tracking():
+    """pan_seg_to_rle_seg + apply_matchers + backward_matching + update_trackers, slice by slice"""
+    from empanada_amd.inference import patterns as PA
+    from empanada_amd.inference import rle
+    g = load_golden('pipeline')
+    for i in range(int(g['n'])):
+        C, ks, head_seed, thing, labels = _params(g, i)
+        shape = g[f'p{i}_lab'].shape
+        trackers = PA.create_axis_trackers({'xy': 0, 'xz': 1, 'yz': 2}, labels, 1000, shape)
+        for name in ('xy', 'xz', 'yz'):
+            pans = g[f'p{i}_{name}_pan'].astype(np.int64)
+            matchers = PA.create_matchers(thing, 1000, 0.25, 0.25)
+            stack = []
+            for pan in pans:
+                stack.append(PA.apply_matchers(rle.pan_seg_to_rle_seg(pan, labels, 1000, thing, True), matchers))
+            fwd = np.stack([rle.rle_seg_to_pan_seg(rs, pans[0].shape) for rs in stack])
+            np.testing.assert_array_equal(fwd, g[f'p{i}_{name}_fwd'])
+            for idx, rs in PA.backward_matching(stack, matchers, len(pans)):
+                PA.update_trackers(rs, idx, trackers[name])
+            bwd = np.stack([rle.rle_seg_to_pan_seg(rs, pans[0].shape) for rs in stack])
+            np.testing.assert_array_equal(bwd, g[f'p{i}_{name}_bwd'])
+            PA.finish_tracking(trackers[name])
+            for tr in trackers[name]:
+                assert_instances_equal(tr.instances, unpack_instances(g, f'p{i}_{name}_tr{tr.class_id}'))
+
+
+def run_fast_pipeline(lab, cls, C, ks, head_seed, thing, labels, min_size=100, min_span=3):
+    from empanada_amd.inference import filters
+    from empanada_amd.inference import patterns as PA
+    from empanada_amd.inference.postprocess import panoptic_stack
+    shape = lab.shape
+    trackers, raw, pans = {}, {}, {}
+    for name in ('xy', 'xz', 'yz'):
+        heads = SY.planted_heads(lab, cls, name, n_classes=C, seed=head_seed, coarse=False)
+        pan, emitted = panoptic_stack(heads['sem'].cuda(), heads['ctr_hmp'].cuda(), heads['offsets'].cuda(),
+                                      thing_list=thing, label_divisor=1000, stuff_area=16, void_label=0,
+                                      nms_threshold=0.1, nms_kernel=7, confidence_thr=0.5, median_kernel_size=ks,
+                                      coarse_boundaries=False)
+        pans[name] = pan
+        trackers[name] = PA.track_stack(pan, name, shape, labels, thing, 1000, 0.25, 0.25)
+        raw[name] = {t.class_id: dict(t.instances) for t in trackers[name]}
+        for t in trackers[name]:
+            filters.remove_small_objects(t, min_size=min_size)
+            filters.remove_pancakes(t, min_span=min_span)
+    cons = {}
+    for cid in labels:
+        cts = PA.get_axis_trackers_by_class(trackers, cid)
+        if cid in thing:
+            con = PA.create_instance_consensus(cts, 2, 0.75, False)
+            filters.remove_small_objects(con, min_size=min_size)
+            filters.remove_pancakes(con, min_span=min_span)
+        else:
+            con = PA.create_semantic_consensus(cts, 2)
+        cons[cid] = con
+    return pans, raw, cons
+
+
+def test_whole_stack_pipeline_matches_reference():
+    from empanada_amd.inference import patterns as PA
+    g = load_golden('pipeline')
+    for i in range(int(g['n'])):
+        C, ks, head_seed, thing, labels = _params(g, i)
+        lab, cls = g[f'p{i}_lab'], g[f'p{i}_cls']
+        pans, raw, cons = run_fast_pipeline(lab, cls, C, ks, head_seed, thing, labels)
+        for name in ('xy', 'xz', 'yz'):
+            np.testing.assert_array_equal(pans[name].cpu().numpy().astype(np.int64), g[f'p{i}_{name}_pan'])
+            for cid in labels:
+                assert_instances_equal(raw[name][cid], unpack_instances(g, f'p{i}_{name}_tr{cid}'))
+        for cid in labels:
+            assert_instances_equal(cons[cid].instances, unpack_instances(g, f'p{i}_con{cid}'))
+            vol = PA.fill_volume_device(lab.shape, [cons[cid]]).cpu().numpy()
+            np.testing.assert_array_equal(vol, g[f'p{i}_vol{cid}'])
+            host = np.zeros(lab.shape, dtype=np.uint32)
+            PA.fill_volume(host, cons[cid].instances)
+            np.testing.assert_array_equal(host, g[f'p{i}_vol{cid}'])
+
+
+def test_consensus_kats():
+    """reference tests/test_consensus.py cases through the product consensus (HIP voting / intersections)"""
+    from empanada_amd import consensus as CO
+    from empanada_amd.array_utils import numpy_fill_instances
+    from empanada_amd.inference import rle, tracker
+    g = load_golden('consensus_kat')
+    vols = g['vols']
+    shape = vols[0].shape
+    trs = [tracker.InstanceTracker(1, 1000, shape, axis='xy') for _ in range(3)]
+    for v, tr in zip(vols, trs):
+        segs, _ = rle.stack_to_rle_segs(torch.from_numpy(v.astype(np.int32)).cuda().view(torch.uint32), [1], 1000,
+                                        [1], force_connected=False)
+        for z in range(shape[0]):
+            tr.update(segs[z][1], z)
+        tr.finish()
+    for j in range(6):
+        vote, iou_thr, bypass = g[f'k{j}_par']
+        inst = CO.merge_objects_from_trackers(trs, int(vote), float(iou_thr), bool(bypass))
+        assert_instances_equal(inst, unpack_instances(g, f'k{j}_inst'))
+        vol = numpy_fill_instances(np.zeros(shape, np.uint32), inst).ravel()
+        np.testing.assert_array_equal(vol, np.repeat(g[f'k{j}_val'], g[f'k{j}_ln']))
+    for j in range(2):
+        strs = []
+        for v in vols:
+            tr = tracker.InstanceTracker(1, 1000, shape, axis='xy')
+            sem = ((v > 0).astype(np.int32) * 1000)
+            segs, _ = rle.stack_to_rle_segs(torch.from_numpy(sem).cuda().view(torch.uint32), [1], 1000, [], False)
+            for z in range(shape[0]):
+                tr.update(segs[z][1], z)
+            tr.finish()
+            strs.append(tr)
+        inst = CO.merge_semantic_from_trackers(strs, int(g[f's{j}_vote']))
+        assert_instances_equal(inst, unpack_instances(g, f's{j}_inst'))
+
+
+def test_trackers_and_chunked_fill():
+    from empanada_amd.inference import rle, tracker
+    from empanada_amd.zarr_utils import ChunkedArray, zarr_fill_instances
+    g = load_golden('trackers')
+    vol = g['vol']
+    for name, ax in (('xy', 0), ('xz', 1), ('yz', 2)):
+        tr = tracker.InstanceTracker(1, 1000, vol.shape, axis=name)
+        stack = np.ascontiguousarray(np.moveaxis(vol, ax, 0)).astype(np.int32)
+        segs, _ = rle.stack_to_rle_segs(torch.from_numpy(stack).cuda().view(torch.uint32), [1], 1000, [1], False)
+        for idx in range(vol.shape[ax]):
+            tr.update(segs[idx][1], idx)
+        tr.finish()
+        assert_instances_equal(tr.instances, unpack_instances(g, f't_{name}'))
+        if name == 'xy':
+            rng = np.random.default_rng(0)
+            for _ in range(4):      # reference tests/test_tracking.py:61-71 with arbitrary chunk shapes
+                chunks = tuple(int(rng.integers(5, s + 1)) for s in vol.shape)
+                arr = ChunkedArray(np.zeros(vol.shape, np.uint32), chunks)
+                zarr_fill_instances(arr, tr.instances, 4)
+                np.testing.assert_array_equal(arr.array, vol)
+
+
+def test_model_forward_matches_cpu_within_tolerance():
+    """D1: fp32 forward on the GPU (MIOpen) vs the same module on the host; tolerance from SURVEY 8(c)."""
+    from empanada_amd.models import PanopticDeepLab, prepare_for_inference, synthesize_weights
+    torch.manual_seed(0)
+    m = synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)).eval()
+    # damp the synthetic head scale so that logits are O(1) like a trained model's
+    with torch.no_grad():
+        for head in (m.semantic_head, m.ins_center, m.ins_xy):
+            head.head[1].weight.mul_(1e-3)
+    x = torch.randn(2, 1, 128, 128)
+    with torch.no_grad():
+        ref = m(x)
+        g = prepare_for_inference(m, 'cuda')
+        out = g(x.cuda().contiguous(memory_format=torch.channels_last))
+    for k in ref:
+        scale = float(ref[k].abs().max())
+        err = float((out[k].float().cpu() - ref[k]).abs().max())
+        assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (k, err, scale)
