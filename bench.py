@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""bench.py -- end-to-end 3D panoptic inference throughput on MI355X (Mvox/s).
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).
+A "step" is one full pass of the hot path over one synthetic volume: model forward over every slice
+(PyTorch-ROCm, fp32, the named architecture with synthesised weights) -> sigmoid -> recursive median +
+harden -> centres -> pixel grouping -> semantic/instance fusion -> runs + 8-connected components ->
+slice-to-slice overlaps -> forward/backward label propagation -> trackers -> size/span filters -> labelled
+uint32 volume written to (pinned) host memory.
+
+Workload at N=1 = BASELINE.json configs[1]: single-GPU stack inference, 256x512x512 volume, ResNet-50 encoder.
+Inputs are resident in HBM when the timed region starts (uint8 EM volume + planted head tensors, see
+empanada_amd/synthetic.py and DESIGN.md "Synthetic workload": the conv forward is computed and timed on every
+slice, its outputs are checksummed, and the post-processing consumes the planted heads so that it sees a
+realistic object load; random weights would give it an empty or degenerate segmentation).
+
+N>1 (launched by torch.distributed.run, one rank per GPU, RCCL): the volume's depth grows with N (weak
+scaling, 256 slices per rank); see DESIGN.md "Multi-GPU".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENGINE = dict(thing_list=[1], label_divisor=20000, stuff_area=64, void_label=0, nms_threshold=0.1, nms_kernel=7,
+              confidence_thr=0.3, median_kernel_size=7)      # projects/mitonet/configs/mmm_median_inference.yaml
+MATCH = dict(merge_iou_thr=0.25, merge_ioa_thr=0.25)
+FILTERS = dict(min_size=500, min_span=4)
+NORM = dict(mean=0.508979, std=0.148561)                      # MitoNet norms
+# algorithmic HBM bytes per voxel of the hand-written kernels (DESIGN.md "Kernels"), C = 1, full-res heads
+ALG_BYTES = {
+    'emp_median_harden_stack': 4 + 1,          # read prob fp32, write sem u8
+    'emp_find_centers': 4,                     # read heatmap
+    'emp_group_pixels': 8 + 2,                 # read offsets, write ids u16
+    'emp_fuse_panoptic': 2 * (1 + 2) + 4,      # hist pass + apply pass read sem u8 + ids u16, write pan u32
+    'emp_runs_count': 4,                       # read pan
+    'emp_runs_extract': 4,                     # read pan (+12 B per run)
+}
+HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--depth', type=int, default=256, help='slices per rank')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--batch', type=int, default=32, help='slices per model call')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
+    ap.add_argument('--cpu-slices', type=int, default=12, help='slices of the same workload for the CPU baseline')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def build_inputs(D, S, device, seed_offset=0):
+    from empanada_amd import synthetic as SY
+    shape = (D, S, S)
+    vol = torch.from_numpy(SY.em_volume(shape, seed=1234 + seed_offset)).to(device)
+    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321 + seed_offset)
+    heads = {'sem': [], 'ctr_hmp': [], 'offsets': []}
+    for s in range(0, D, 64):                    # chunked to bound the generator's temporaries
+        h = SY.planted_heads(lab, cls, 'xy', device=device, slices=slice(s, min(D, s + 64)), seed=99 + s)
+        for k in heads:
+            heads[k].append(h[k])
+    heads = {k: torch.cat(v, dim=0).contiguous() for k, v in heads.items()}
+    return vol, heads, int(cls.shape[0] - 1)
+
+
+class Pipeline:
+    def __init__(self, args, device):
+        from empanada_amd.models import PanopticDeepLab, prepare_for_inference, synthesize_weights
+        self.dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[args.dtype]
+        model = synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1))
+        with torch.no_grad():                     # O(1) logits like a trained model (synthetic He weights are hot)
+            for head in (model.semantic_head, model.ins_center, model.ins_xy):
+                head.head[1].weight.mul_(1e-3)
+        self.model = prepare_for_inference(model, device, self.dtype)
+        self.device = device
+        self.batch = args.batch
+        self.timers = {}
+
+    @torch.no_grad()
+    def forward(self, vol):
+        """uint8 (D,H,W) resident volume -> resident sem probabilities (D,1,H,W) fp32 + a checksum of all heads"""
+        D, H, W = vol.shape
+        prob = torch.empty((D, 1, H, W), dtype=torch.float32, device=self.device)
+        chk = torch.zeros((), dtype=torch.float64, device=self.device)
+        a = 1.0 / (255.0 * NORM['std'])
+        b = -NORM['mean'] / NORM['std']
+        for s in range(0, D, self.batch):
+            x = vol[s:s + self.batch].unsqueeze(1).to(self.dtype).mul_(a).add_(b)
+            x = x.contiguous(memory_format=torch.channels_last)
+            out = self.model(x)
+            prob[s:s + self.batch] = torch.sigmoid(out['sem_logits'].float())
+            chk += out['ctr_hmp'].float().sum(dtype=torch.float64) + out['offsets'].float().sum(dtype=torch.float64)
+        return prob, chk + prob.sum(dtype=torch.float64)
+
+    def postprocess(self, heads, shape3d):
+        from empanada_amd.inference import filters
+        from empanada_amd.inference import patterns as PA
+        from empanada_amd.inference.postprocess import panoptic_stack
+        t0 = time.perf_counter()
+        pan, _ = panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'], coarse_boundaries=False, **ENGINE)
+        trackers = PA.track_stack(pan, 'xy', shape3d, [1], ENGINE['thing_list'], ENGINE['label_divisor'], **MATCH)
+        t1 = time.perf_counter()
+        for tr in trackers:
+            filters.remove_small_objects(tr, FILTERS['min_size'])
+            filters.remove_pancakes(tr, FILTERS['min_span'])
+        vol = PA.fill_volume_device(shape3d, trackers)
+        self.timers.setdefault('track_host_s', []).append(t1 - t0)
+        return vol, trackers
+
+
+def cpu_baseline(args, vol_u8, heads, n_slices):
+    """The oracle chain (CPU restatement of the reference) + torch-CPU forward on a bounded sample of the
+    same workload: the first n_slices slices.  kind = 'port'."""
+    from empanada_amd.models import PanopticDeepLab, synthesize_weights
+    from oracle import postprocess as OP
+    from oracle import rle_ops as OR
+    from oracle import rle_seg as OS
+    n = min(n_slices, vol_u8.shape[0])
+    model = synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)).eval()
+    x = vol_u8[:n].cpu().float().unsqueeze(1)
+    x = (x - 255 * NORM['mean']) / (255 * NORM['std'])
+    sem, ctr, off = (heads[k][:n].cpu().numpy() for k in ('sem', 'ctr_hmp', 'offsets'))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(n):
+            out = model(x[i:i + 1])
+            _ = torch.sigmoid(out['sem_logits'])
+    t_conv = time.perf_counter() - t0
+    pans = OP.engine3d_stack([sem[t:t + 1] for t in range(n)], [ctr[t:t + 1] for t in range(n)],
+                             [off[t:t + 1] for t in range(n)], coarse_boundaries=False, render=True, **ENGINE)
+    pans = [p.squeeze() for p in pans]
+    matchers = OS.create_matchers(ENGINE['thing_list'], ENGINE['label_divisor'], MATCH['merge_iou_thr'],
+                                  MATCH['merge_ioa_thr'])
+    stack = OS.forward_matching(pans, matchers, [1], ENGINE['label_divisor'], ENGINE['thing_list'])
+    shape = (len(pans),) + pans[0].shape
+    trs = OS.create_axis_trackers(['xy'], [1], ENGINE['label_divisor'], shape)['xy']
+    for idx, rs in OS.backward_matching(stack, matchers, len(pans)):
+        OS.update_trackers(rs, idx, trs)
+    OS.finish_tracking(trs)
+    for tr in trs:
+        OS.remove_small_objects(tr, FILTERS['min_size'])
+        OS.remove_pancakes(tr, FILTERS['min_span'])
+    out = np.zeros(shape, dtype=np.uint32)
+    for tr in trs:
+        OR.numpy_fill_instances(out, tr.instances)
+    dt = time.perf_counter() - t0
+    vox = float(np.prod(shape))
+    return {'value': round(vox / dt / 1e6, 4), 'unit': 'Mvox/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'first {len(pans)} of {vol_u8.shape[0]} slices ({shape[1]}x{shape[2]}), same heads; '
+                      f'conv {t_conv:.1f}s of {dt:.1f}s', 'objects': int(sum(len(t.instances) for t in trs))}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    from empanada_amd import _hip
+    _hip.load()
+    torch.backends.cudnn.benchmark = True
+
+    D, S = args.depth, args.size
+    vol, heads, n_obj = build_inputs(D, S, device, seed_offset=rank)
+    pipe = Pipeline(args, device)
+    host_out = torch.empty((D, S, S), dtype=torch.int32).pin_memory()
+    shape3d = (D, S, S)
+
+    def step():
+        prob, chk = pipe.forward(vol)
+        out, trackers = pipe.postprocess(heads, shape3d)
+        host_out.copy_(out.view(torch.int32), non_blocking=True)
+        return chk, trackers
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        chk, trackers = step()
+    barrier()
+    _hip.PROFILE = {}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[3 * k].record()
+        prob, chk = pipe.forward(vol)
+        ev[3 * k + 1].record()
+        out, trackers = pipe.postprocess(heads, shape3d)
+        host_out.copy_(out.view(torch.int32), non_blocking=True)
+        ev[3 * k + 2].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, _hip.PROFILE = _hip.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        vox_total = float(D) * S * S * world * args.steps
+        ms_step = dt / args.steps * 1e3
+        fwd_ms = np.mean([ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(args.steps)])
+        post_ms = np.mean([ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(args.steps)])
+        kern = {name: float(np.mean([a.elapsed_time(b) for a, b in evs])) for name, evs in prof.items()}
+        per_call = {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}
+        # dominant hand-written kernel among the per-voxel ones
+        dom = max((k for k in kern if k in ALG_BYTES), key=lambda k: kern[k])
+        alg = ALG_BYTES[dom] * float(D) * S * S
+        ach = alg / (kern[dom] * 1e-3) / 1e9
+        flops = 414477.0 * D * S * S                                      # PDL-R50, C=1
+        res = {
+            'metric': 'Mvox/s end-to-end 3D panoptic inference (incl. consensus); PQ vs CPU ref',
+            'value': round(vox_total / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_step, 2), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'stack (xy) inference, {D * world}x{S}x{S} uint8 volume, PanopticDeepLab/ResNet-50 '
+                                   f'C=1 fp-forward on every slice + HIP post-processing on planted heads '
+                                   f'(ks=7, full-res heads), {n_obj} planted objects per rank',
+                       'mode': 'stack', 'slices_per_rank': D, 'batch': args.batch,
+                       'objects_found': int(sum(len(t.instances) for t in trackers))},
+            'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'postprocess_to_host': round(float(post_ms), 2),
+                             'host_chain_s': round(float(np.mean(pipe.timers['track_host_s'][-args.steps:])), 4),
+                             'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2)},
+            'hip_calls_ms': per_call,
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'alg_bytes_per_voxel': ALG_BYTES[dom]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res['cpu_baseline'] = cpu_baseline(args, vol, heads, args.cpu_slices)
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -107,10 +107,23 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# optional per-call HIP-event timing (bench.py): name -> list of (start_event, end_event).  Events are recorded
+# on the stream the kernels are launched on (torch's current stream) and only read after the final sync.
+PROFILE = None
+
+
 def call(name, *args):
     """Call an int-returning ABI function; raise HipError with emp_last_error() on failure."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if PROFILE is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        PROFILE.setdefault(name, []).append((e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise HipError(f"{name} failed ({rc}): {lib.emp_last_error().decode()}")
 

@@ -90,9 +90,14 @@ def zarr_fill_instances(array, instances, processes=4):
                     keep = (zs >= z1) & (zs < z2) & (ys >= y1) & (ys < y2) & (xs >= x1) & (xs < x2)
                     if not keep.any():
                         continue
+                    # like fill_zarr_mp (:71-84) the chunk-local start and END are unravelled separately; a run
+                    # that leaves its chunk and comes back (row wrap over a narrow last chunk) is therefore
+                    # painted exactly as the reference paints it
+                    ze, ye, xe = np.unravel_index(rng[keep, 1] - 1, array.shape)
                     starts = np.ravel_multi_index((zs[keep] - z1, ys[keep] - y1, xs[keep] - x1), cshape)
+                    ends = np.ravel_multi_index((ze - z1, ye - y1, xe - x1), cshape, mode='wrap') + 1
                     sub[instance_id] = {'starts': starts.astype(np.int64),
-                                        'runs': (rng[keep, 1] - rng[keep, 0]).astype(np.int64)}
+                                        'runs': np.maximum(ends - starts, 0).astype(np.int64)}
                 if sub:
                     array[sl] = numpy_fill_instances(seg, sub).reshape(cshape)
 

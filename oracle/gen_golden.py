@@ -469,6 +469,32 @@ def main():
     cr2 = np.array(ZU.chunk_ranges(cr, 20 * 28, 7 * 28))
     cr3 = np.array(ZU.chunk_ranges(cr2, 28, 10))
     cases.update({'z_ranges': rr, 'z_c1': cr, 'z_c2': cr2, 'z_c3': cr3, 'z_chunks': np.array([5, 7, 10])})
+    # Z1 zarr_fill_instances on a numpy-backed array with the zarr.Array attributes it reads; the process pool
+    # is run serially (an in-memory array cannot be shared with worker processes)
+    class _Arr:
+        def __init__(self, shape, chunks):
+            import math
+            self.a = np.zeros(shape, np.uint32); self.shape = shape; self.chunks = chunks
+            self.nchunks = math.prod(math.ceil(s / c) for s, c in zip(shape, chunks))
+        def __getitem__(self, i): return self.a[i]
+        def __setitem__(self, i, v): self.a[i] = v
+    class _SerialPool:
+        def __init__(self, n): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def map(self, f, it): return [f(x) for x in it]
+    ZU.Pool = _SerialPool
+    tr = TR.InstanceTracker(1, 1000, vol.shape, axis='xy')
+    for idx in range(vol.shape[0]):
+        tr.update(RL.pan_seg_to_rle_seg(vol[idx], [1], 1000, [1], False)[1], idx)
+    tr.finish()
+    zchunks = [(22, 15, 17), (10, 9, 5), (6, 5, 9), (21, 15, 26), (24, 20, 28), (1, 20, 28), (7, 20, 27)]
+    for j, ch in enumerate(zchunks):
+        arr = _Arr(vol.shape, ch)
+        ZU.zarr_fill_instances(arr, tr.instances, 4)
+        cases[f'zf{j}_chunks'] = np.array(ch)
+        cases[f'zf{j}_vol'] = arr.a
+    cases['zf_n'] = np.array(len(zchunks))
     _save('trackers', **cases)
 
 
