@@ -109,13 +109,18 @@ class Pipeline:
         from empanada_amd.inference.postprocess import panoptic_stack
         t0 = time.perf_counter()
         pan, _ = panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'], coarse_boundaries=False, **ENGINE)
-        trackers = PA.track_stack(pan, 'xy', shape3d, [1], ENGINE['thing_list'], ENGINE['label_divisor'], **MATCH)
+        torch.cuda.synchronize()
+        st = {'panoptic_stack_incl_wait_for_forward': time.perf_counter() - t0}
+        trackers = PA.track_stack(pan, 'xy', shape3d, [1], ENGINE['thing_list'], ENGINE['label_divisor'], timers=st,
+                                  **MATCH)
         t1 = time.perf_counter()
         for tr in trackers:
             filters.remove_small_objects(tr, FILTERS['min_size'])
             filters.remove_pancakes(tr, FILTERS['min_span'])
         vol = PA.fill_volume_device(shape3d, trackers)
+        st['filters_and_fill_launch'] = time.perf_counter() - t1
         self.timers.setdefault('track_host_s', []).append(t1 - t0)
+        self.timers.setdefault('stages', []).append(st)
         return vol, trackers
 
 
@@ -161,6 +166,13 @@ def cpu_baseline(args, vol_u8, heads, n_slices):
                       f'conv {t_conv:.1f}s of {dt:.1f}s', 'objects': int(sum(len(t.instances) for t in trs))}
 
 
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -177,7 +189,9 @@ def main():
     torch.backends.cudnn.benchmark = True
 
     D, S = args.depth, args.size
+    log(f'building inputs {D}x{S}x{S}')
     vol, heads, n_obj = build_inputs(D, S, device, seed_offset=rank)
+    log(f'inputs ready ({n_obj} planted objects); building model')
     pipe = Pipeline(args, device)
     host_out = torch.empty((D, S, S), dtype=torch.int32).pin_memory()
     shape3d = (D, S, S)
@@ -194,8 +208,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        chk, trackers = step()
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
+        prob, chk = pipe.forward(vol)
+        torch.cuda.synchronize()
+        log(f'warmup {i}: forward {time.perf_counter() - t_w:.2f}s')
+        out, trackers = pipe.postprocess(heads, shape3d)
+        host_out.copy_(out.view(torch.int32), non_blocking=True)
+        torch.cuda.synchronize()
+        log(f'warmup {i}: total {time.perf_counter() - t_w:.2f}s')
     barrier()
     _hip.PROFILE = {}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
@@ -209,6 +230,7 @@ def main():
         ev[3 * k + 2].record()
     barrier()
     dt = time.perf_counter() - t0
+    log(f'timed {args.steps} steps in {dt:.2f}s')
     prof, _hip.PROFILE = _hip.PROFILE, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -239,13 +261,16 @@ def main():
                        'objects_found': int(sum(len(t.instances) for t in trackers))},
             'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'postprocess_to_host': round(float(post_ms), 2),
                              'host_chain_s': round(float(np.mean(pipe.timers['track_host_s'][-args.steps:])), 4),
-                             'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2)},
+                             'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2),
+                             'host_stages_s': {k: round(float(np.mean([s[k] for s in pipe.timers['stages'][-args.steps:]])), 4)
+                                               for k in pipe.timers['stages'][-1]}},
             'hip_calls_ms': per_call,
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
                          'alg_bytes_per_voxel': ALG_BYTES[dom]},
         }
         if not args.no_cpu_baseline and world == 1:
+            log('cpu baseline')
             res['cpu_baseline'] = cpu_baseline(args, vol, heads, args.cpu_slices)
         else:
             res['cpu_baseline'] = None

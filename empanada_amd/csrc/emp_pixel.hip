@@ -462,11 +462,16 @@ __device__ __forceinline__ void wave_hist_add(int32_t *base, int64_t key, bool v
     }
 }
 
+// Histogram pass.  Each block owns a contiguous span of one slice and accumulates into an LDS
+// histogram ((cap+1)*nc instance/class bins + nc stuff bins) that is flushed once with global atomics
+// (non-zero bins only); without LDS (huge cap) it adds to the global bins directly.
 __global__ __launch_bounds__(256) void fuse_hist_kernel(const uint8_t *__restrict__ sem,
                                                         const uint16_t *__restrict__ ids, int H, int W, int up,
                                                         int cap, int nc, uint32_t thing_mask,
-                                                        int32_t *__restrict__ hist, int32_t *__restrict__ stuff)
+                                                        int32_t *__restrict__ hist, int32_t *__restrict__ stuff,
+                                                        int use_lds)
 {
+    extern __shared__ int32_t lh[];
     const int d = blockIdx.y;
     const int64_t HW = (int64_t)H * W;
     const int w = W / up;
@@ -474,12 +479,20 @@ __global__ __launch_bounds__(256) void fuse_hist_kernel(const uint8_t *__restric
     const uint16_t *g = ids + (int64_t)d * (H / up) * w;
     int32_t *hh = hist + (int64_t)d * (cap + 1) * nc;
     int32_t *ss = stuff + (int64_t)d * nc;
-    // whole waves iterate together so that the ballots see uniform control flow
-    int64_t span = (int64_t)gridDim.x * blockDim.x;
-    int64_t iters = (HW + span - 1) / span;
-    for (int64_t it = 0; it < iters; ++it) {
-        int64_t p = it * span + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        bool live = p < HW;
+    const int n_hist = (cap + 1) * nc;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < n_hist + nc; i += blockDim.x) lh[i] = 0;
+        __syncthreads();
+    }
+    int32_t *bh = use_lds ? lh : hh;
+    int32_t *bs = use_lds ? lh + n_hist : ss;
+    // contiguous span per block; whole waves iterate together so that the ballots see uniform control flow
+    const int64_t span = (HW + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * span;
+    const int64_t p1 = (p0 + span < HW) ? p0 + span : HW;
+    for (int64_t q = p0; q < p1; q += blockDim.x) {
+        int64_t p = q + threadIdx.x;
+        bool live = p < p1;
         int c = 0, ins = 0;
         if (live) {
             c = s[p];
@@ -488,8 +501,19 @@ __global__ __launch_bounds__(256) void fuse_hist_kernel(const uint8_t *__restric
             int id = g[(int64_t)(y / up) * w + x / up];
             ins = ((thing_mask >> c) & 1u) ? id : 0;
         }
-        wave_hist_add(hh, (int64_t)ins * nc + c, live && ins > 0);
-        wave_hist_add(ss, (int64_t)c, live && ins == 0);
+        wave_hist_add(bh, (int64_t)ins * nc + c, live && ins > 0);
+        wave_hist_add(bs, (int64_t)c, live && ins == 0);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_hist; i += blockDim.x) {
+            int v = lh[i];
+            if (v) atomicAdd(hh + i, v);
+        }
+        if (threadIdx.x < nc) {
+            int v = lh[n_hist + threadIdx.x];
+            if (v) atomicAdd(ss + threadIdx.x, v);
+        }
     }
 }
 
@@ -589,8 +613,16 @@ extern "C" int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D,
         EMP_FAIL(EMP_ELAUNCH, "fuse: memset failed");
     int64_t HW = (int64_t)H * W;
     int gx = emp_grid(HW, 256, 1024);
-    hipLaunchKernelGGL(fuse_hist_kernel, dim3(gx, D), dim3(256), 0, st, sem, ids, H, W, up, cap, n_classes,
-                       thing_mask, work + L.hist, work + L.stuff);
+    {
+        // ~8K pixels per block keeps the flush cheap; D * gh blocks fill the chip
+        int gh = (int)emp_cdiv(HW, 8192);
+        if ((int64_t)gh * D < 1024) gh = (int)emp_cdiv(1024, D);
+        if (gh > gx) gh = gx;
+        size_t lds = ((size_t)(cap + 1) * n_classes + n_classes) * sizeof(int32_t);
+        int use_lds = lds <= 48 * 1024;
+        hipLaunchKernelGGL(fuse_hist_kernel, dim3(gh, D), dim3(256), use_lds ? lds : 0, st, sem, ids, H, W, up, cap,
+                           n_classes, thing_mask, work + L.hist, work + L.stuff, use_lds);
+    }
     EMP_CHECK_LAUNCH("emp_fuse_panoptic(hist)");
     hipLaunchKernelGGL(fuse_lut_kernel, dim3(D), dim3(256), 0, st, cap, n_classes, thing_mask, label_divisor,
                        stuff_area, work + L.hist, work + L.stuff, work + L.lut, work + L.ok);

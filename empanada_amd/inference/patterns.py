@@ -280,16 +280,26 @@ class _ClassChain:
 
 
 def track_stack(pan, axis_name, shape3d, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25,
-                return_table=False):
+                return_table=False, timers=None):
     """Panoptic label stack of one plane (D,H,W uint32, device) -> finished InstanceTrackers, one per label.
 
     Equivalent to, slice by slice: pan_seg_to_rle_seg(force_connected=True) -> apply_matchers (forward) ->
     backward_matching -> update_trackers -> finish_tracking (scripts/pdl_inference3d.py:163-198).
     """
+    import time
+    _t = [time.perf_counter()]
+
+    def _lap(name):
+        if timers is not None:
+            now = time.perf_counter()
+            timers[name] = timers.get(name, 0.0) + now - _t[0]
+            _t[0] = now
+
     labels = list(labels)
     thing_list = list(thing_list)
     D, H, W = pan.shape
     table = _hip.extract_runs(pan, label_divisor, [l for l in labels if l in thing_list])
+    _lap('extract_runs')
     trip = _hip.overlap_next(table, label_divisor).cpu().numpy() if D > 1 and table.n_comp else np.zeros((0, 3), np.int32)
     nc = table.n_comp
     c_slice = table.c_slice.cpu().numpy()
@@ -299,6 +309,7 @@ def track_stack(pan, axis_name, shape3d, labels, thing_list, label_divisor, merg
     r_val = table.r_val.cpu().numpy()
     c_cls = (r_val[table.c_first.cpu().numpy()].astype(np.int64) // label_divisor) if nc else np.zeros(0, np.int64)
     S = coo_matrix((trip[:, 2].astype(np.int64), (trip[:, 0], trip[:, 1])), shape=(max(nc, 1), max(nc, 1))).tocsr()
+    _lap('overlaps_and_tables_to_host')
 
     def overlap_fwd(t, comps_t, comps_t1):
         if not len(comps_t) or not len(comps_t1):
@@ -328,8 +339,10 @@ def track_stack(pan, axis_name, shape3d, labels, thing_list, label_divisor, merg
                     first_seen[l][lab] = seq
                     seq += 1
 
+    _lap('matching_chain')
     trackers = _assemble_trackers(table, comp_final, c_slice, c_cls, c_box, first_seen, axis_name, shape3d, labels,
                                   label_divisor)
+    _lap('assemble_trackers')
     return (trackers, table, comp_final) if return_table else trackers
 
 

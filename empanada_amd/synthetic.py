@@ -91,15 +91,15 @@ def planted_heads(labels, classes, axis, *, n_classes=1, sigma=6.0, noise=0.05, 
     n = int(classes.shape[0])
     cls = torch.as_tensor(classes.astype(np.int64), device=device)
 
-    # per (slice, id) centroid of the 2D cross-section
-    key = (torch.arange(S, device=device).view(S, 1, 1) * n + lab.long()).reshape(-1)
-    ys = torch.arange(H, device=device, dtype=torch.float64).view(1, H, 1).expand(S, H, W).reshape(-1)
-    xs = torch.arange(W, device=device, dtype=torch.float64).view(1, 1, W).expand(S, H, W).reshape(-1)
-    cnt = torch.zeros(S * n, dtype=torch.float64, device=device).index_add_(0, key, torch.ones_like(ys))
-    sy = torch.zeros(S * n, dtype=torch.float64, device=device).index_add_(0, key, ys)
-    sx = torch.zeros(S * n, dtype=torch.float64, device=device).index_add_(0, key, xs)
-    cy = (sy / cnt.clamp(min=1)).view(S, n)
-    cx = (sx / cnt.clamp(min=1)).view(S, n)
+    # per (slice, id) centroid of the 2D cross-section: integer sums over the object pixels only
+    # (float64 atomics on the shared background key are pathologically slow on the GPU)
+    zi, yi, xi = torch.nonzero(lab > 0, as_tuple=True)
+    key = zi * n + lab[zi, yi, xi].long()
+    cnt = torch.zeros(S * n, dtype=torch.int64, device=device).index_add_(0, key, torch.ones_like(key))
+    sy = torch.zeros(S * n, dtype=torch.int64, device=device).index_add_(0, key, yi)
+    sx = torch.zeros(S * n, dtype=torch.int64, device=device).index_add_(0, key, xi)
+    cy = (sy.double() / cnt.clamp(min=1).double()).view(S, n)
+    cx = (sx.double() / cnt.clamp(min=1).double()).view(S, n)
     present = (cnt.view(S, n) > 0)
     present[:, 0] = False
 
