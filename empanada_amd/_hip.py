@@ -37,7 +37,7 @@ SIGNATURES = {
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
     'emp_find_centers': (_I, [_P, _I, _I, _I, _F, _I, _I, _P, _P, _P]),
-    'emp_group_pixels': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    'emp_group_pixels': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _U32, _P, _P]),
     'emp_fuse_work_elems': (_L, [_I, _I, _I]),
     'emp_fuse_panoptic': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _U32, _L, _L, _L, _P, _P, _P, _P]),
     'emp_runs_count': (_I, [_P, _I, _I, _I, _P, _P]),
@@ -168,14 +168,19 @@ def find_centers(hmp, thr, k, cap=1024):
     return idx, cnt
 
 
-def group_pixels(idx, cnt, offsets, step):
-    """offsets (D,2,h,w) fp32 -> ids (D,h,w) uint16."""
+def group_pixels(idx, cnt, offsets, step, sem=None, thing_list=()):
+    """offsets (D,2,h,w) fp32 -> ids (D,h,w) uint16.  sem (D,h,w) u8 restricts the vote to thing pixels."""
     require_gpu()
     D, _, h, w = offsets.shape
     offsets = offsets.contiguous()
     ids = torch.empty((D, h, w), dtype=torch.uint16, device=offsets.device)
-    call('emp_group_pixels', _ptr(idx), _ptr(cnt), idx.shape[1], _ptr(offsets), D, h, w, int(step), _ptr(ids),
-         stream())
+    mask = 0
+    for t in thing_list:
+        mask |= 1 << int(t)
+    if sem is not None:
+        assert sem.shape == (D, h, w) and sem.dtype == torch.uint8
+    call('emp_group_pixels', _ptr(idx), _ptr(cnt), idx.shape[1], _ptr(offsets), D, h, w, int(step),
+         _ptr(sem.contiguous()) if sem is not None else None, mask, _ptr(ids), stream())
     return ids
 
 

@@ -256,6 +256,20 @@ __global__ __launch_bounds__(256) void find_centers_kernel(const float *__restri
     const int pad = k / 2;
     const int th = CT_H + k - 1, tw = CT_W + k - 1;
     const float *img = hmp + (int64_t)d * h * w;
+    // Fast path: most tiles of a centre heatmap hold nothing above the threshold.  Every thread checks the
+    // 4 output pixels it owns with one coalesced pass (no halo); a tile without candidates retires here,
+    // so the common case costs exactly the algorithmic 4 B/pixel.
+    {
+        bool cand = false;
+        for (int i = threadIdx.x; i < CT_H * CT_W; i += blockDim.x) {
+            int y = ty0 + i / CT_W, x = tx0 + i % CT_W;
+            if (y < h && x < w) {
+                float v = img[(int64_t)y * w + x];
+                cand = cand || (v > thr && v > 0.0f);
+            }
+        }
+        if (!__syncthreads_or(cand)) return;
+    }
     for (int i = threadIdx.x; i < th * tw; i += blockDim.x) {
         int ly = i / tw, lx = i % tw;
         int y = ty0 - pad + ly, x = tx0 - pad + lx;
@@ -349,7 +363,8 @@ extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr
 __global__ __launch_bounds__(256) void group_pixels_kernel(const int32_t *__restrict__ ctr_idx,
                                                            const int32_t *__restrict__ ctr_count, int cap,
                                                            const float *__restrict__ offsets, int h, int w,
-                                                           int step, uint16_t *__restrict__ out_ids)
+                                                           int step, const uint8_t *__restrict__ sem,
+                                                           uint32_t thing_mask, uint16_t *__restrict__ out_ids)
 {
     __shared__ float2 ctr[EMP_MAX_CENTERS];
     const int d = blockIdx.y;
@@ -371,29 +386,39 @@ __global__ __launch_bounds__(256) void group_pixels_kernel(const int32_t *__rest
     int64_t base = ((int64_t)blockIdx.x * blockDim.x) * GP_PPT + threadIdx.x;
     float ly[GP_PPT], lx[GP_PPT], sb[GP_PPT], db[GP_PPT];
     int id[GP_PPT];
+    bool want[GP_PPT];
+    bool any_want = false;
+    const uint8_t *sm = sem ? sem + (int64_t)d * hw : nullptr;
 #pragma unroll
     for (int j = 0; j < GP_PPT; ++j) {
         int64_t p = base + (int64_t)j * blockDim.x;
         bool live = p < hw;
+        // with a semantic map only thing pixels are voted on: every consumer masks the ids by
+        // "class is a thing" (postprocess.py:221, engines.py:280-285), the others are written as 0
+        want[j] = live && (!sm || ((thing_mask >> sm[p]) & 1u));
+        any_want = any_want || want[j];
         int y = live ? (int)(p / w) : 0, x = live ? (int)(p % w) : 0;
-        float oy = live ? offy[p] : 0.f, ox = live ? offx[p] : 0.f;
+        float oy = want[j] ? offy[p] : 0.f, ox = want[j] ? offx[p] : 0.f;
         ly[j] = __fadd_rn((float)(y * step), oy);  // coord + offsets
         lx[j] = __fadd_rn((float)(x * step), ox);
         sb[j] = INFINITY;
         db[j] = dinit;
-        id[j] = idinit;
+        id[j] = want[j] ? idinit : 0;
     }
-    for (int k = 0; k < K; ++k) {
-        float2 c = ctr[k];
+    // whole waves without a thing pixel skip the centre loop (wave-uniform branch)
+    if (__any(any_want)) {
+        for (int k = 0; k < K; ++k) {
+            float2 c = ctr[k];
 #pragma unroll
-        for (int j = 0; j < GP_PPT; ++j) {
-            float dy = __fsub_rn(c.x, ly[j]);
-            float dx = __fsub_rn(c.y, lx[j]);
-            float s = __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
-            if (s < sb[j]) {
-                sb[j] = s;
-                float dd = __fsqrt_rn(s);
-                if (dd < db[j]) { db[j] = dd; id[j] = k + 1; }
+            for (int j = 0; j < GP_PPT; ++j) {
+                float dy = __fsub_rn(c.x, ly[j]);
+                float dx = __fsub_rn(c.y, lx[j]);
+                float s = __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
+                if (want[j] && s < sb[j]) {
+                    sb[j] = s;
+                    float dd = __fsqrt_rn(s);
+                    if (dd < db[j]) { db[j] = dd; id[j] = k + 1; }
+                }
             }
         }
     }
@@ -405,8 +430,8 @@ __global__ __launch_bounds__(256) void group_pixels_kernel(const int32_t *__rest
 }
 
 extern "C" int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count, int cap,
-                                const float *offsets, int D, int h, int w, int step, uint16_t *out_ids,
-                                void *stream)
+                                const float *offsets, int D, int h, int w, int step, const uint8_t *sem,
+                                uint32_t thing_mask, uint16_t *out_ids, void *stream)
 {
     EMP_REQUIRE(ctr_idx && ctr_count && offsets && out_ids, "group_pixels: null pointer");
     EMP_REQUIRE(cap >= 1 && cap <= EMP_MAX_CENTERS, "group_pixels: cap %d not in 1..%d", cap, EMP_MAX_CENTERS);
@@ -417,7 +442,7 @@ extern "C" int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count
     int64_t hw = (int64_t)h * w;
     int gx = (int)emp_cdiv(hw, 256 * GP_PPT);
     hipLaunchKernelGGL(group_pixels_kernel, dim3(gx, D), dim3(256), 0, emp_stream(stream), ctr_idx, ctr_count,
-                       cap, offsets, h, w, step, out_ids);
+                       cap, offsets, h, w, step, sem, thing_mask, out_ids);
     EMP_CHECK_LAUNCH("emp_group_pixels");
     return EMP_OK;
 }
@@ -594,6 +619,132 @@ __global__ __launch_bounds__(256) void fuse_apply_kernel(const uint8_t *__restri
     }
 }
 
+// 4 pixels per lane: one 4-byte class load, one 8-byte (or 2-byte when up is a multiple of 4) id load,
+// one 16-byte label store -- 1 KiB of output per wave instruction.  Requires W % 4 == 0 and up in {1, 4k}.
+template <typename OutT>
+__global__ __launch_bounds__(256) void fuse_apply_vec4_kernel(const uint8_t *__restrict__ sem,
+                                                              const uint16_t *__restrict__ ids, int H, int W, int up,
+                                                              int cap, int nc, uint32_t thing_mask, int64_t div,
+                                                              int64_t void_label, const int32_t *__restrict__ lut,
+                                                              const int32_t *__restrict__ ok, OutT *__restrict__ out)
+{
+    const int d = blockIdx.y;
+    const int64_t HW = (int64_t)H * W;
+    const int w = W / up;
+    const uint8_t *s = sem + (int64_t)d * HW;
+    const uint16_t *g = ids + (int64_t)d * (H / up) * w;
+    const uint32_t *ll = reinterpret_cast<const uint32_t *>(lut) + (int64_t)d * (cap + 1);
+    const int32_t *oo = ok + (int64_t)d * nc;
+    OutT *o = out + (int64_t)d * HW;
+    const int64_t n4 = HW / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = q * 4;
+        uchar4 c4 = *reinterpret_cast<const uchar4 *>(s + p);
+        int cls[4] = {c4.x, c4.y, c4.z, c4.w};
+        int id[4];
+        const int y = (int)(p / W), x = (int)(p % W);
+        if (up == 1) {
+            ushort4 i4 = *reinterpret_cast<const ushort4 *>(g + p);
+            id[0] = i4.x; id[1] = i4.y; id[2] = i4.z; id[3] = i4.w;
+        } else {
+            int v = g[(int64_t)(y / up) * w + x / up];
+            id[0] = id[1] = id[2] = id[3] = v;
+        }
+        OutT r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = cls[j] < nc ? cls[j] : nc - 1;
+            int ins = ((thing_mask >> c) & 1u) ? id[j] : 0;
+            int64_t v = ins > 0 ? (int64_t)ll[ins] : (oo[c] ? (int64_t)c * div : void_label);
+            r[j] = (OutT)v;
+        }
+        if (sizeof(OutT) == 4) {
+            *reinterpret_cast<uint4 *>(o + p) = make_uint4((uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[p + j] = r[j];
+        }
+    }
+}
+
+// 4 pixels per lane for the histogram pass (same loads as above); sub-position j of all lanes is
+// aggregated across the wave before touching the block-local LDS bins.
+__global__ __launch_bounds__(256) void fuse_hist_vec4_kernel(const uint8_t *__restrict__ sem,
+                                                             const uint16_t *__restrict__ ids, int H, int W, int up,
+                                                             int cap, int nc, uint32_t thing_mask,
+                                                             int32_t *__restrict__ hist, int32_t *__restrict__ stuff)
+{
+    extern __shared__ int32_t lh[];
+    const int d = blockIdx.y;
+    const int64_t HW = (int64_t)H * W;
+    const int w = W / up;
+    const uint8_t *s = sem + (int64_t)d * HW;
+    const uint16_t *g = ids + (int64_t)d * (H / up) * w;
+    int32_t *hh = hist + (int64_t)d * (cap + 1) * nc;
+    int32_t *ss = stuff + (int64_t)d * nc;
+    const int n_hist = (cap + 1) * nc;
+    for (int i = threadIdx.x; i < n_hist + nc; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const int64_t n4 = HW / 4;
+    const int64_t span = (n4 + gridDim.x - 1) / gridDim.x;
+    const int64_t q0 = (int64_t)blockIdx.x * span;
+    const int64_t q1 = (q0 + span < n4) ? q0 + span : n4;
+    for (int64_t qq = q0; qq < q1; qq += blockDim.x) {
+        int64_t q = qq + threadIdx.x;
+        bool live = q < q1;
+        int cls[4] = {0, 0, 0, 0}, id[4] = {0, 0, 0, 0};
+        if (live) {
+            const int64_t p = q * 4;
+            uchar4 c4 = *reinterpret_cast<const uchar4 *>(s + p);
+            cls[0] = c4.x; cls[1] = c4.y; cls[2] = c4.z; cls[3] = c4.w;
+            if (up == 1) {
+                ushort4 i4 = *reinterpret_cast<const ushort4 *>(g + p);
+                id[0] = i4.x; id[1] = i4.y; id[2] = i4.z; id[3] = i4.w;
+            } else {
+                int y = (int)(p / W), x = (int)(p % W);
+                int v = g[(int64_t)(y / up) * w + x / up];
+                id[0] = id[1] = id[2] = id[3] = v;
+            }
+        }
+        // fold the lane's own 4 pixels first when they agree (the common case), else add them one by one
+        int c0 = cls[0] < nc ? cls[0] : nc - 1;
+        int i0 = ((thing_mask >> c0) & 1u) ? id[0] : 0;
+        bool same = true;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) same = same && (cls[j] == cls[0]) && (id[j] == id[0]);
+        if (__all(same || !live)) {
+            const int lane = threadIdx.x & 63;
+            int64_t key = (i0 > 0) ? (int64_t)i0 * nc + c0 : (int64_t)n_hist + c0;
+            int64_t prev = __shfl_up(key, 1);
+            bool pvalid = __shfl_up((int)live, 1) != 0;
+            bool head = live && (lane == 0 || !pvalid || prev != key);
+            unsigned long long heads = __ballot(head), valids = __ballot(live);
+            if (head) {
+                unsigned long long stop = (heads | ~valids) & ~((2ULL << lane) - 1ULL);
+                int end = stop ? __ffsll((long long)stop) - 1 : 64;
+                atomicAdd(&lh[key], 4 * (end - lane));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int c = cls[j] < nc ? cls[j] : nc - 1;
+                int ins = ((thing_mask >> c) & 1u) ? id[j] : 0;
+                wave_hist_add(lh, (int64_t)ins * nc + c, live && ins > 0);
+                wave_hist_add(lh + n_hist, (int64_t)c, live && ins == 0);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_hist; i += blockDim.x) {
+        int v = lh[i];
+        if (v) atomicAdd(hh + i, v);
+    }
+    if (threadIdx.x < nc) {
+        int v = lh[n_hist + threadIdx.x];
+        if (v) atomicAdd(ss + threadIdx.x, v);
+    }
+}
+
 extern "C" int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D, int H, int W, int up, int cap,
                                  int n_classes, uint32_t thing_mask, int64_t label_divisor, int64_t stuff_area,
                                  int64_t void_label, int32_t *work, uint32_t *out_pan_u32,
@@ -613,6 +764,10 @@ extern "C" int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D,
         EMP_FAIL(EMP_ELAUNCH, "fuse: memset failed");
     int64_t HW = (int64_t)H * W;
     int gx = emp_grid(HW, 256, 1024);
+    // 4-pixel-per-lane kernels need aligned rows and ids that are either per pixel or shared by the 4 pixels
+    const bool vec4 = (W % 4 == 0) && (up == 1 || up % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(sem) & 3) == 0) && ((reinterpret_cast<uintptr_t>(ids) & 7) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(out_pan_u32 ? (void *)out_pan_u32 : (void *)out_pan_i64) & 15) == 0);
     {
         // ~8K pixels per block keeps the flush cheap; D * gh blocks fill the chip
         int gh = (int)emp_cdiv(HW, 8192);
@@ -620,14 +775,28 @@ extern "C" int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D,
         if (gh > gx) gh = gx;
         size_t lds = ((size_t)(cap + 1) * n_classes + n_classes) * sizeof(int32_t);
         int use_lds = lds <= 48 * 1024;
-        hipLaunchKernelGGL(fuse_hist_kernel, dim3(gh, D), dim3(256), use_lds ? lds : 0, st, sem, ids, H, W, up, cap,
-                           n_classes, thing_mask, work + L.hist, work + L.stuff, use_lds);
+        if (vec4 && use_lds)
+            hipLaunchKernelGGL(fuse_hist_vec4_kernel, dim3(gh, D), dim3(256), lds, st, sem, ids, H, W, up, cap,
+                               n_classes, thing_mask, work + L.hist, work + L.stuff);
+        else
+            hipLaunchKernelGGL(fuse_hist_kernel, dim3(gh, D), dim3(256), use_lds ? lds : 0, st, sem, ids, H, W, up,
+                               cap, n_classes, thing_mask, work + L.hist, work + L.stuff, use_lds);
     }
     EMP_CHECK_LAUNCH("emp_fuse_panoptic(hist)");
     hipLaunchKernelGGL(fuse_lut_kernel, dim3(D), dim3(256), 0, st, cap, n_classes, thing_mask, label_divisor,
                        stuff_area, work + L.hist, work + L.stuff, work + L.lut, work + L.ok);
     EMP_CHECK_LAUNCH("emp_fuse_panoptic(lut)");
-    if (out_pan_u32)
+    if (vec4) {
+        int gv = emp_grid(HW / 4, 256, 1024);
+        if (out_pan_u32)
+            hipLaunchKernelGGL(fuse_apply_vec4_kernel<uint32_t>, dim3(gv, D), dim3(256), 0, st, sem, ids, H, W, up,
+                               cap, n_classes, thing_mask, label_divisor, void_label, work + L.lut, work + L.ok,
+                               out_pan_u32);
+        else
+            hipLaunchKernelGGL(fuse_apply_vec4_kernel<int64_t>, dim3(gv, D), dim3(256), 0, st, sem, ids, H, W, up,
+                               cap, n_classes, thing_mask, label_divisor, void_label, work + L.lut, work + L.ok,
+                               out_pan_i64);
+    } else if (out_pan_u32)
         hipLaunchKernelGGL(fuse_apply_kernel<uint32_t>, dim3(gx, D), dim3(256), 0, st, sem, ids, H, W, up, cap,
                            n_classes, thing_mask, label_divisor, void_label, work + L.lut, work + L.ok,
                            out_pan_u32);

@@ -173,7 +173,9 @@ def panoptic_stack(sem_prob, ctr_hmp, offsets, *, thing_list, label_divisor=1000
     sem = _hip.median_harden_stack(sem_prob, ks, confidence_thr)
     step = 4 if coarse_boundaries else 1
     idx, cnt = centers_batched(ctr_hmp, nms_threshold, nms_kernel)
-    ids = _hip.group_pixels(idx, cnt, _cuda(offsets).float().contiguous(), step)
+    # full-resolution heads: only thing pixels are voted on (the fusion masks the rest anyway)
+    ids = _hip.group_pixels(idx, cnt, _cuda(offsets).float().contiguous(), step,
+                            sem=sem if (step == 1 and upsampling == 1) else None, thing_list=thing_list)
     if n_classes is None:
         n_classes = max(2 if C == 1 else C, max(thing_list) + 1)
     pan = _hip.fuse_panoptic(sem, ids, idx.shape[1], n_classes, thing_list, label_divisor, stuff_area, void_label,

@@ -80,10 +80,13 @@ int emp_find_centers(const float *hmp, int D, int h, int w, float thr, int k, in
  *      d = sqrtf(fmaf(dx, dx, dy*dy)),  dy = step*cy - (step*y + off_y), dx likewise
  * (the rounding torch.norm performs on the reference's CPU path); when K > 20 a pixel whose
  * every d >= 1e5 keeps id 0 (chunked path, :97-111).  K = min(count, cap); K == 0 -> ids 0.
+ * sem (D, h, w) u8 or NULL: when given (same resolution as the offsets), pixels whose class bit is
+ * clear in thing_mask are not voted on and get id 0 -- every consumer multiplies the ids by the
+ * thing mask anyway (postprocess.py:221, engines.py:280-285), so results downstream are unchanged.
  * out_ids (D, h, w) uint16.                                                                     */
 int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count, int cap,
-                     const float *offsets, int D, int h, int w, int step, uint16_t *out_ids,
-                     void *stream);
+                     const float *offsets, int D, int h, int w, int step, const uint8_t *sem,
+                     uint32_t thing_mask, uint16_t *out_ids, void *stream);
 
 /* ---- P4b + P5: instance cells -> panoptic labels -------------------------------------------
  * replaces get_instance_cells (nearest upsample)   engines.py:257-275

@@ -116,6 +116,22 @@ def test_group_pixels_golden(hip):
         np.testing.assert_array_equal(got, g[f'g{i}_ids'], err_msg=f'case {i}')
 
 
+def test_group_pixels_thing_mask(hip):
+    """with a semantic map, non-thing pixels are skipped (id 0); thing pixels are unchanged"""
+    from oracle import postprocess as OP
+    rng = np.random.default_rng(77)
+    h, w, K = 70, 132, 37
+    ctr = np.stack([rng.integers(0, h, K), rng.integers(0, w, K)], axis=1).astype(np.int64)
+    off = rng.normal(0, 5, (1, 2, h, w)).astype(np.float32)
+    sem = np.repeat(np.repeat(rng.integers(0, 3, (h // 10, w // 12)), 10, 0), 12, 1).astype(np.uint8)
+    exp = OP.group_pixels(ctr, off, step=1)[0] * np.isin(sem, [1])
+    idx = torch.from_numpy((ctr[:, 0] * w + ctr[:, 1]).astype(np.int32))[None].cuda()
+    cnt = torch.tensor([K], dtype=torch.int32).cuda()
+    ids = hip.group_pixels(idx, cnt, torch.from_numpy(off).cuda(), 1, sem=torch.from_numpy(sem)[None].cuda(),
+                           thing_list=[1])
+    np.testing.assert_array_equal(ids[0].cpu().numpy().astype(np.int64), exp)
+
+
 @pytest.mark.parametrize('K,step', [(1, 1), (20, 1), (21, 1), (333, 1), (64, 4), (7, 4)])
 def test_group_pixels_vs_oracle(hip, K, step):
     from oracle import postprocess as OP
@@ -137,10 +153,12 @@ def test_fuse_golden_and_random(hip):
         cases.append((g[f'm{i}_sem'][0], g[f'm{i}_ins'][0], [int(t) for t in g[f'm{i}_thing']], div, stuff, void,
                       g[f'm{i}_pan'][0]))
     rng = np.random.default_rng(9)
-    for (thing, nc, K) in [([1], 2, 30), ([1, 2, 4], 5, 200), ([2], 3, 3)]:
-        H, W = 64, 96
-        sem = np.repeat(np.repeat(rng.integers(0, nc, (H // 4, W // 8)), 4, 0), 8, 1).astype(np.int64)
-        ids = np.repeat(np.repeat(rng.integers(0, K + 1, (H // 8, W // 4)), 8, 0), 4, 1).astype(np.int64)
+    for (thing, nc, K, W) in [([1], 2, 30, 96), ([1, 2, 4], 5, 200, 96), ([2], 3, 3, 96), ([1, 2], 4, 40, 54),
+                              ([1], 2, 700, 200)]:
+        H = 64
+        sem = np.repeat(np.repeat(rng.integers(0, nc, (H // 4, W // 8 + 1)), 4, 0), 8, 1)[:, :W].astype(np.int64)
+        ids = np.repeat(np.repeat(rng.integers(0, K + 1, (H // 8, W // 4 + 1)), 8, 0), 4, 1)[:, :W].astype(np.int64)
+        ids[::7, ::5] = rng.integers(0, K + 1, ids[::7, ::5].shape)      # break the 4-pixel uniformity
         ins = ids * np.isin(sem, thing)
         exp = OP.merge_semantic_and_instance(sem[None], ins[None], 1000, thing, 40, 0)[0]
         cases.append((sem, ids, thing, 1000, 40, 0, exp))
