@@ -204,6 +204,18 @@ def forward_multigpu(matchers, queue, rle_stack, matcher_in, confidence_thr, med
 
 
 # ----------------------------------------------------------------------------- whole-stack path
+class _Inst:
+    """Ordered instances of one slice for one class, as parallel arrays: labels (int64, dict order),
+    comps (flat component ids) with seg (start of each instance's components), areas (int64)."""
+    __slots__ = ('labels', 'comps', 'seg', 'areas')
+
+    def __init__(self, labels, comps, seg, areas):
+        self.labels, self.comps, self.seg, self.areas = labels, comps, seg, areas
+
+    def __len__(self):
+        return len(self.labels)
+
+
 class _ClassChain:
     """Forward + backward label propagation for one thing class on component tables.
 
@@ -220,62 +232,110 @@ class _ClassChain:
         self.ioa_thr = merge_ioa_thr
         self.next_label = class_id * label_divisor + 1
 
-    def _match(self, target, match, overlap, assign_new):
-        """target/match: ordered {label: (comps, area)}; overlap(ta, mb) -> dense (len(ta), len(mb)) int64 of
-        component overlaps (target comps x match comps).  Returns ordered {new_label: (comps, area)}."""
-        t_labels = np.array(list(target.keys()))
-        m_labels = list(match.keys())
-        if len(t_labels) == 0 or len(m_labels) == 0:
-            matched = (np.array([]), np.array([]))
-            ioa = np.array([])
-        else:
-            t_comps = [c for comps, _ in target.values() for c in comps]
-            m_comps = [c for comps, _ in match.values() for c in comps]
-            ov = overlap(t_comps, m_comps)
-            t_seg = np.cumsum([0] + [len(c) for c, _ in target.values()])[:-1]
-            m_seg = np.cumsum([0] + [len(c) for c, _ in match.values()])[:-1]
-            inter = np.add.reduceat(np.add.reduceat(ov, t_seg, axis=0), m_seg, axis=1)
-            t_area = np.array([a for _, a in target.values()], dtype=np.int64)
-            m_area = np.array([a for _, a in match.values()], dtype=np.int64)
+    def _match(self, target, match, inter, assign_new):
+        """target/match: _Inst; inter: (len(target), len(match)) int64 instance intersections.
+        Returns the relabelled (and possibly merged) match instances as a new _Inst."""
+        nt, nm = len(target), len(match)
+        if nm == 0:
+            return match
+        new_labels = None
+        if nt > 0:
+            nzr, nzc = np.nonzero(inter)
             iou = np.zeros(inter.shape, dtype='float')
             ioa = np.zeros(inter.shape, dtype=np.float32)
-            r, c = np.nonzero(inter)
-            iou[r, c] = inter[r, c] / (t_area[r] + m_area[c] - inter[r, c])
-            ioa[r, c] = inter[r, c] / m_area[c]
-            rows, cols = linear_sum_assignment(iou, maximize=True)
-            keep = iou[rows, cols] >= self.iou_thr
-            rows, cols = rows[keep], cols[keep]
-            matched = (t_labels[rows], np.array(m_labels)[cols])
-        new_labels, self.next_label = assign_labels(m_labels, t_labels, matched, ioa, self.ioa_thr, assign_new,
-                                                    self.next_label)
-        out = {}
-        for nl, (comps, area) in zip(new_labels, match.values()):
-            nl = int(nl)
-            if nl not in out:
-                out[nl] = (list(comps), area)
+            iv = inter[nzr, nzc]
+            iou[nzr, nzc] = iv / (target.areas[nzr] + match.areas[nzc] - iv)
+            ioa[nzr, nzc] = iv / match.areas[nzc]
+            if len(nzr) and (np.bincount(nzr, minlength=nt).max() > 1 or np.bincount(nzc, minlength=nm).max() > 1):
+                rows, cols = linear_sum_assignment(iou, maximize=True)
+                keep = iou[rows, cols] >= self.iou_thr
+                rows, cols = rows[keep], cols[keep]
             else:
-                out[nl] = (out[nl][0] + list(comps), out[nl][1] + area)
-        return out
+                # at most one overlap per row and column: the maximum-weight assignment is forced to
+                # contain every positive entry (any alternative has a smaller sum), so the pairs that
+                # survive the IoU filter are exactly the positive entries above the threshold
+                keep = iou[nzr, nzc] >= self.iou_thr
+                rows, cols = nzr[keep], nzc[keep]
+            new_labels = np.full(nm, -1, dtype=np.int64)
+            new_labels[cols] = target.labels[rows]
+            un = np.flatnonzero(new_labels < 0)
+            if len(un):
+                ioa_max = ioa[:, un].max(axis=0)
+                merge = ioa_max >= self.ioa_thr
+                new_labels[un[merge]] = target.labels[ioa[:, un[merge]].argmax(axis=0)]
+                rest = un[~merge]
+            else:
+                rest = un
+        else:
+            new_labels = np.full(nm, -1, dtype=np.int64)
+            rest = np.arange(nm)
+            if 0 >= self.ioa_thr:            # ioa_max = 0 (matcher.py:303) passes a non-positive threshold and the
+                raise ValueError("attempt to get argmax of an empty sequence")     # reference fails on the empty argmax
+        if len(rest):
+            if assign_new:
+                new_labels[rest] = self.next_label + np.arange(len(rest))
+                self.next_label += len(rest)
+            else:
+                new_labels[rest] = match.labels[rest]
+        # instances that received the same label are merged, in order of first appearance
+        uniq, first, inv = np.unique(new_labels, return_index=True, return_inverse=True)
+        if len(uniq) == nm:
+            return _Inst(new_labels, match.comps, match.seg, match.areas)
+        order = np.argsort(first, kind='stable')             # groups in order of first appearance
+        rank = np.empty(len(uniq), dtype=np.int64)
+        rank[order] = np.arange(len(uniq))
+        grp = rank[inv]                                       # group index of every match instance
+        sizes = np.diff(np.concatenate([match.seg, [len(match.comps)]]))
+        inst_order = np.argsort(grp, kind='stable')           # instances by group, original order inside
+        comp_src = np.concatenate([np.arange(match.seg[i], match.seg[i] + sizes[i]) for i in inst_order])
+        gsizes = np.bincount(grp, weights=sizes, minlength=len(uniq)).astype(np.int64)
+        seg = np.concatenate([[0], np.cumsum(gsizes)[:-1]]).astype(np.int64)
+        areas = np.bincount(grp, weights=match.areas, minlength=len(uniq)).astype(np.int64)
+        return _Inst(uniq[order], match.comps[comp_src], seg, areas)
 
-    def run(self, slices, overlap_fwd):
-        """slices[t]: ordered {cc_label: ([comp], area)} for this class; overlap_fwd(t, comps_t, comps_t1) gives
-        the overlap matrix between comps of slice t (rows) and slice t+1 (cols).  Returns the per-slice
-        instance dicts after the backward pass (patterns.py:102-121 semantics)."""
+    def run(self, slices, pair_matrix):
+        """slices[t]: _Inst of the slice's connected components (ascending cc label = dict order);
+        pair_matrix(t) -> (n_t, n_t1) int64 overlaps between the components of slice t and t+1, indexed by the
+        components' positions in slices[t] / slices[t+1].  pos[comp] gives that position.
+        Returns the per-slice instances after the backward pass (patterns.py:102-121 semantics)."""
         n = len(slices)
         if n == 0:
             return []
+        pos = self.pos
+
+        def inter_of(M, row_inst, col_inst):
+            """sum the component overlaps M over the components of each row / column instance"""
+            R = M[pos[row_inst.comps]]
+            if len(row_inst.seg) != len(row_inst.comps):
+                R = np.add.reduceat(R, row_inst.seg, axis=0)
+            C = R[:, pos[col_inst.comps]]
+            if len(col_inst.seg) != len(col_inst.comps):
+                C = np.add.reduceat(C, col_inst.seg, axis=1)
+            return C
+
         fwd = [None] * n
         fwd[0] = slices[0]
         if len(fwd[0]) > 0:
-            self.next_label = max(fwd[0].keys()) + 1
+            self.next_label = int(fwd[0].labels.max()) + 1
+        mats = [None] * n
         for t in range(1, n):
-            fwd[t] = self._match(fwd[t - 1], slices[t], lambda ta, mb, t=t: overlap_fwd(t - 1, ta, mb), True)
+            M = pair_matrix(t - 1)
+            mats[t - 1] = M
+            if len(fwd[t - 1]) and len(slices[t]):
+                inter = inter_of(M, fwd[t - 1], slices[t])
+            else:
+                inter = np.zeros((len(fwd[t - 1]), len(slices[t])), dtype=np.int64)
+            fwd[t] = self._match(fwd[t - 1], slices[t], inter, True)
         bwd = [None] * n
         bwd[n - 1] = fwd[n - 1]
         if len(bwd[n - 1]) > 0:
-            self.next_label = max(bwd[n - 1].keys()) + 1
+            self.next_label = int(bwd[n - 1].labels.max()) + 1
         for t in range(n - 2, -1, -1):
-            bwd[t] = self._match(bwd[t + 1], fwd[t], lambda ta, mb, t=t: overlap_fwd(t, mb, ta).T, False)
+            if len(bwd[t + 1]) and len(fwd[t]):
+                inter = inter_of(mats[t].T, bwd[t + 1], fwd[t])      # rows: slice t+1 groups, cols: slice t groups
+            else:
+                inter = np.zeros((len(bwd[t + 1]), len(fwd[t])), dtype=np.int64)
+            bwd[t] = self._match(bwd[t + 1], fwd[t], inter, False)
         return bwd
 
 
@@ -302,42 +362,61 @@ def track_stack(pan, axis_name, shape3d, labels, thing_list, label_divisor, merg
     _lap('extract_runs')
     trip = _hip.overlap_next(table, label_divisor).cpu().numpy() if D > 1 and table.n_comp else np.zeros((0, 3), np.int32)
     nc = table.n_comp
-    c_slice = table.c_slice.cpu().numpy()
+    c_slice = table.c_slice.cpu().numpy().astype(np.int64)
     c_label = table.c_label.cpu().numpy()
     c_area = table.c_area.cpu().numpy()
     c_box = table.c_box.cpu().numpy()
     r_val = table.r_val.cpu().numpy()
     c_cls = (r_val[table.c_first.cpu().numpy()].astype(np.int64) // label_divisor) if nc else np.zeros(0, np.int64)
-    S = coo_matrix((trip[:, 2].astype(np.int64), (trip[:, 0], trip[:, 1])), shape=(max(nc, 1), max(nc, 1))).tocsr()
     _lap('overlaps_and_tables_to_host')
 
-    def overlap_fwd(t, comps_t, comps_t1):
-        if not len(comps_t) or not len(comps_t1):
-            return np.zeros((len(comps_t), len(comps_t1)), dtype=np.int64)
-        return np.asarray(S[comps_t][:, comps_t1].todense(), dtype=np.int64)
-
-    # per slice / class: components in ascending label order (= dict order of pan_seg_to_rle_seg)
-    order = np.lexsort((c_label, c_cls, c_slice)) if nc else np.zeros(0, np.int64)
     comp_final = np.zeros(nc, dtype=np.int64)        # final label per component
-    first_seen = {l: {} for l in labels}             # label -> order of first tracker.update (slice desc, dict order)
-    per_class = {l: [dict() for _ in range(D)] for l in labels}
-    for c in order:
-        k = int(c_cls[c])
-        if k in per_class:
-            per_class[k][int(c_slice[c])][int(c_label[c])] = ([int(c)], int(c_area[c]))
+    first_seen = {}                                  # class -> (labels, sequence number of first tracker.update)
     for l in labels:
+        sel = np.flatnonzero(c_cls == l)
+        # per slice: components in ascending label order (= dict order of pan_seg_to_rle_seg)
+        sel = sel[np.lexsort((c_label[sel], c_slice[sel]))]
+        bounds = np.searchsorted(c_slice[sel], np.arange(D + 1))
+        pos = np.zeros(max(nc, 1), dtype=np.int64)
+        pos[sel] = np.arange(len(sel)) - bounds[c_slice[sel]]
+        slices = []
+        for t in range(D):
+            cs = sel[bounds[t]:bounds[t + 1]]
+            slices.append(_Inst(c_label[cs], cs, np.arange(len(cs), dtype=np.int64), c_area[cs]))
         if l in thing_list:
+            # overlap triplets of this class, grouped by the slice of the first component
+            ta, tb, tv = trip[:, 0].astype(np.int64), trip[:, 1].astype(np.int64), trip[:, 2].astype(np.int64)
+            m = c_cls[ta] == l if len(ta) else np.zeros(0, dtype=bool)
+            ta, tb, tv = ta[m], tb[m], tv[m]
+            o = np.argsort(c_slice[ta], kind='stable') if len(ta) else np.zeros(0, np.int64)
+            ta, tb, tv = ta[o], tb[o], tv[o]
+            tb_bounds = np.searchsorted(c_slice[ta], np.arange(D + 1)) if len(ta) else np.zeros(D + 1, np.int64)
+            pa, pb = pos[ta], pos[tb]
+
+            def pair_matrix(t, bounds=bounds, tb_bounds=tb_bounds, pa=pa, pb=pb, tv=tv):
+                n0, n1 = bounds[t + 1] - bounds[t], bounds[t + 2] - bounds[t + 1]
+                M = np.zeros((n0, n1), dtype=np.int64)
+                lo, hi = tb_bounds[t], tb_bounds[t + 1]
+                if hi > lo:
+                    np.add.at(M, (pa[lo:hi], pb[lo:hi]), tv[lo:hi])
+                return M
+
             chain = _ClassChain(l, label_divisor, merge_iou_thr, merge_ioa_thr)
-            result = chain.run(per_class[l], overlap_fwd)
+            chain.pos = pos
+            result = chain.run(slices, pair_matrix)
         else:
-            result = per_class[l]
-        seq = 0
+            result = slices
+        lab_seq, seen = [], set()
         for t in range(D - 1, -1, -1):
-            for lab, (comps, _) in result[t].items():
-                comp_final[comps] = lab
-                if lab not in first_seen[l]:
-                    first_seen[l][lab] = seq
-                    seq += 1
+            inst = result[t]
+            if len(inst):
+                sizes = np.diff(np.concatenate([inst.seg, [len(inst.comps)]]))
+                comp_final[inst.comps] = np.repeat(inst.labels, sizes)
+                for lab in inst.labels.tolist():
+                    if lab not in seen:
+                        seen.add(lab)
+                        lab_seq.append(lab)
+        first_seen[l] = {lab: i for i, lab in enumerate(lab_seq)}
 
     _lap('matching_chain')
     trackers = _assemble_trackers(table, comp_final, c_slice, c_cls, c_box, first_seen, axis_name, shape3d, labels,
@@ -396,13 +475,25 @@ def _assemble_trackers(table, comp_final, c_slice, c_cls, c_box, first_seen, axi
             lab_vals = lb[np.concatenate([[0], cuts])]
             st_parts = np.split(st3, cuts)
             ln_parts = np.split(ln3, cuts)
-            # boxes: merge of the per-slice 3D boxes of the member components
+            # boxes: merge of the per-slice 3D boxes of the member components (to_box3d + merge_boxes)
             csel = np.flatnonzero(c_cls == l)
+            cl = comp_final[csel]
+            co = np.argsort(cl, kind='stable')
+            cl, cb, csl = cl[co], c_box[csel][co].astype(np.int64), c_slice[csel][co]
+            bc = np.concatenate([[0], np.flatnonzero(np.diff(cl)) + 1])
+            lo2 = np.minimum.reduceat(cb[:, :2], bc, axis=0)
+            hi2 = np.maximum.reduceat(cb[:, 2:], bc, axis=0)
+            s_lo = np.minimum.reduceat(csl, bc)
+            s_hi = np.maximum.reduceat(csl, bc) + 1
             boxes = {}
-            for c in csel:
-                b3 = to_box3d(int(c_slice[c]), tuple(int(v) for v in c_box[c]), axis_name)
-                lab = int(comp_final[c])
-                boxes[lab] = b3 if lab not in boxes else merge_boxes(b3, boxes[lab])
+            for lab, (h1, w1), (h2, w2), a0, a1 in zip(cl[bc].tolist(), lo2.tolist(), hi2.tolist(), s_lo.tolist(),
+                                                         s_hi.tolist()):
+                if axis_name == 'xy':
+                    boxes[lab] = (a0, h1, w1, a1, h2, w2)
+                elif axis_name == 'xz':
+                    boxes[lab] = (h1, a0, w1, h2, a1, w2)
+                else:
+                    boxes[lab] = (h1, w1, a0, h2, w2, a1)
             inst = {int(lab): {'box': boxes[int(lab)], 'starts': s, 'runs': r}
                     for lab, s, r in zip(lab_vals, st_parts, ln_parts)}
             for lab in sorted(inst, key=lambda k: first_seen[l][k]):
