@@ -237,68 +237,72 @@ extern "C" int emp_median_step(const float *const *slices_host, int ks, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------
-// P3: centre NMS.  Block = 256 threads, output tile 16 x 64; the thresholded tile + halo is
-// staged in LDS, the k x k maximum is separable (row max, then column max).
-#define CT_H 16
-#define CT_W 64
+// P3: centre NMS, streaming form.  A centre must exceed the threshold and be a maximum of its k x k
+// window, so it is in particular >= its in-row neighbours.  Each lane streams 4 pixels (one 16-byte
+// load, 1 KiB per wave instruction), tests that cheap necessary condition in registers, and only the
+// few survivors (a handful per object) check the full window straight from L2/L1.  Traffic is the
+// algorithmic 4 B/pixel; the windowed maximum is never materialised.
 #define CT_MAXK 15
 
-__global__ __launch_bounds__(256) void find_centers_kernel(const float *__restrict__ hmp, int h, int w,
-                                                           float thr, int k, int cap,
-                                                           int32_t *__restrict__ out_idx,
-                                                           int32_t *__restrict__ out_count, int tiles_x)
+__device__ __forceinline__ float thresholded(float v, float thr) { return (v > thr) ? v : -1.0f; }
+
+__device__ __forceinline__ bool is_window_max(const float *__restrict__ img, int h, int w, int y, int x, float v,
+                                              float thr, int k)
 {
-    __shared__ float tile[(CT_H + CT_MAXK - 1) * (CT_W + CT_MAXK - 1)];
-    __shared__ float rowmax[(CT_H + CT_MAXK - 1) * CT_W];
-    const int d = blockIdx.y;
-    const int ty0 = (blockIdx.x / tiles_x) * CT_H;
-    const int tx0 = (blockIdx.x % tiles_x) * CT_W;
     const int pad = k / 2;
-    const int th = CT_H + k - 1, tw = CT_W + k - 1;
+    for (int dy = 0; dy < k; ++dy) {
+        int yy = y - pad + dy;
+        if (yy < 0 || yy >= h) continue;
+        const float *row = img + (int64_t)yy * w;
+        for (int dx = 0; dx < k; ++dx) {
+            int xx = x - pad + dx;
+            if (xx < 0 || xx >= w) continue;
+            if (thresholded(row[xx], thr) > v) return false;
+        }
+    }
+    return true;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void find_centers_kernel(const float *__restrict__ hmp, int h, int w, float thr,
+                                                           int k, int cap, int32_t *__restrict__ out_idx,
+                                                           int32_t *__restrict__ out_count)
+{
+    const int d = blockIdx.y;
     const float *img = hmp + (int64_t)d * h * w;
-    // Fast path: most tiles of a centre heatmap hold nothing above the threshold.  Every thread checks the
-    // 4 output pixels it owns with one coalesced pass (no halo); a tile without candidates retires here,
-    // so the common case costs exactly the algorithmic 4 B/pixel.
-    {
-        bool cand = false;
-        for (int i = threadIdx.x; i < CT_H * CT_W; i += blockDim.x) {
-            int y = ty0 + i / CT_W, x = tx0 + i % CT_W;
-            if (y < h && x < w) {
-                float v = img[(int64_t)y * w + x];
-                cand = cand || (v > thr && v > 0.0f);
+    const int64_t hw = (int64_t)h * w;
+    const int lane = threadIdx.x & 63;
+    const bool need_left = (k / 2) >= 1, need_right = (k - 1 - k / 2) >= 1;
+    // wave-uniform loop bounds: all 64 lanes take part in the shuffles of every iteration
+    const int64_t wave_q0 = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * VEC;
+    for (int64_t base = wave_q0; base < hw; base += (int64_t)gridDim.x * blockDim.x * VEC) {
+        const int64_t q = base + (int64_t)lane * VEC;
+        bool live = q < hw;
+        float v[VEC + 2];
+        if (VEC == 4) {
+            float4 f = live ? *reinterpret_cast<const float4 *>(img + q) : make_float4(-1.f, -1.f, -1.f, -1.f);
+            v[1] = f.x; v[2] = f.y; v[3] = f.z; v[4] = f.w;
+        } else {
+            v[1] = live ? img[q] : -1.f;
+        }
+        const int y = live ? (int)(q / w) : 0, x = live ? (int)(q % w) : 0;
+        float left = __shfl_up(v[VEC], 1), right = __shfl_down(v[1], 1);
+        // neighbours across the wave edge or the row edge come from memory (or do not exist)
+        if (lane == 0 || x == 0) left = (live && x > 0) ? img[q - 1] : -INFINITY;
+        if (lane == 63 || x + VEC >= w) right = (live && x + VEC < w) ? img[q + VEC] : -INFINITY;
+        v[0] = left;
+        v[VEC + 1] = right;
+        if (!live) continue;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float c = v[j + 1];
+            if (!(c > thr && c > 0.0f)) continue;
+            if (need_left && x + j > 0 && thresholded(v[j], thr) > c) continue;
+            if (need_right && x + j + 1 < w && thresholded(v[j + 2], thr) > c) continue;
+            if (is_window_max(img, h, w, y, x + j, c, thr, k)) {
+                int slot = atomicAdd(&out_count[d], 1);
+                if (slot < cap) out_idx[(int64_t)d * cap + slot] = y * w + x + j;
             }
-        }
-        if (!__syncthreads_or(cand)) return;
-    }
-    for (int i = threadIdx.x; i < th * tw; i += blockDim.x) {
-        int ly = i / tw, lx = i % tw;
-        int y = ty0 - pad + ly, x = tx0 - pad + lx;
-        float v = -INFINITY;
-        if (y >= 0 && y < h && x >= 0 && x < w) {
-            v = img[(int64_t)y * w + x];
-            v = (v > thr) ? v : -1.0f;  // F.threshold(h, thr, -1)
-        }
-        tile[i] = v;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < th * CT_W; i += blockDim.x) {
-        int ly = i / CT_W, lx = i % CT_W;
-        float m = -INFINITY;
-        for (int j = 0; j < k; ++j) m = fmaxf(m, tile[ly * tw + lx + j]);
-        rowmax[i] = m;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < CT_H * CT_W; i += blockDim.x) {
-        int ly = i / CT_W, lx = i % CT_W;
-        int y = ty0 + ly, x = tx0 + lx;
-        if (y >= h || x >= w) continue;
-        float v = tile[(ly + pad) * tw + lx + pad];
-        if (!(v > 0.0f)) continue;
-        float m = -INFINITY;
-        for (int j = 0; j < k; ++j) m = fmaxf(m, rowmax[(ly + j) * CT_W + lx]);
-        if (v == m) {
-            int slot = atomicAdd(&out_count[d], 1);
-            if (slot < cap) out_idx[(int64_t)d * cap + slot] = y * w + x;
         }
     }
 }
@@ -344,9 +348,17 @@ extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr
     hipStream_t st = emp_stream(stream);
     if (hipMemsetAsync(out_count, 0, sizeof(int32_t) * D, st) != hipSuccess)
         EMP_FAIL(EMP_ELAUNCH, "find_centers: memset failed");
-    int tiles_x = (w + CT_W - 1) / CT_W, tiles_y = (h + CT_H - 1) / CT_H;
-    hipLaunchKernelGGL(find_centers_kernel, dim3(tiles_x * tiles_y, D), dim3(256), 0, st, hmp, h, w, thr, k,
-                       cap, out_idx, out_count, tiles_x);
+    const bool vec4 = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(hmp) & 15) == 0);
+    const int64_t hw = (int64_t)h * w;
+    if (vec4) {
+        int gx = emp_grid(hw / 4, 256, 512);
+        hipLaunchKernelGGL(find_centers_kernel<4>, dim3(gx, D), dim3(256), 0, st, hmp, h, w, thr, k, cap, out_idx,
+                           out_count);
+    } else {
+        int gx = emp_grid(hw, 256, 1024);
+        hipLaunchKernelGGL(find_centers_kernel<1>, dim3(gx, D), dim3(256), 0, st, hmp, h, w, thr, k, cap, out_idx,
+                           out_count);
+    }
     EMP_CHECK_LAUNCH("emp_find_centers");
     hipLaunchKernelGGL(sort_centers_kernel, dim3(D), dim3(256), 0, st, out_idx, out_count, cap);
     EMP_CHECK_LAUNCH("emp_find_centers(sort)");
@@ -358,7 +370,12 @@ extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr
 // sit in LDS (broadcast reads).  Exact rounding contract (see emp_hip.h):
 //   s = fmaf(dx, dx, fl(dy*dy)); d = sqrt_rn(s); first strictly smaller d wins.
 // sqrt is monotone, so d is only evaluated when s improves on the best s so far.
-#define GP_PPT 4
+// Work compaction: a block owns GP_TILE consecutive pixels.  Pixels that need a vote (all of them without a
+// semantic map, only thing pixels with one -- ~10 % of an EM slice) are compacted into an LDS list so that the
+// K-centre loop runs with full lanes; ids are staged in LDS and written back as one coalesced 16-byte store
+// per lane.  Traffic: 1 B (class) + 8 B (offsets, voted pixels only) read, 2 B written per pixel.
+#define GP_TILE 2048
+#define GP_PER_THREAD (GP_TILE / 256)
 
 __global__ __launch_bounds__(256) void group_pixels_kernel(const int32_t *__restrict__ ctr_idx,
                                                            const int32_t *__restrict__ ctr_count, int cap,
@@ -367,11 +384,15 @@ __global__ __launch_bounds__(256) void group_pixels_kernel(const int32_t *__rest
                                                            uint32_t thing_mask, uint16_t *__restrict__ out_ids)
 {
     __shared__ float2 ctr[EMP_MAX_CENTERS];
+    __shared__ uint16_t todo[GP_TILE];
+    __shared__ __attribute__((aligned(16))) uint16_t ids_tile[GP_TILE];
+    __shared__ int n_todo;
     const int d = blockIdx.y;
     int K = ctr_count[d];
     if (K > cap) K = cap;
     const int64_t hw = (int64_t)h * w;
     const float fstep = (float)step;
+    if (threadIdx.x == 0) n_todo = 0;
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
         int f = ctr_idx[(int64_t)d * cap + i];
         // step * ctr: int64 * python float -> fp32 tensor (postprocess.py:151)
@@ -381,51 +402,75 @@ __global__ __launch_bounds__(256) void group_pixels_kernel(const int32_t *__rest
     const float *offy = offsets + (int64_t)d * 2 * hw;
     const float *offx = offy + hw;
     uint16_t *out = out_ids + (int64_t)d * hw;
+    const uint8_t *sm = sem ? sem + (int64_t)d * hw : nullptr;
+    const int64_t tile0 = (int64_t)blockIdx.x * GP_TILE;
     const float dinit = (K > 20) ? 1e5f : INFINITY;
     const int idinit = (K > 20 || K == 0) ? 0 : 1;
-    int64_t base = ((int64_t)blockIdx.x * blockDim.x) * GP_PPT + threadIdx.x;
-    float ly[GP_PPT], lx[GP_PPT], sb[GP_PPT], db[GP_PPT];
-    int id[GP_PPT];
-    bool want[GP_PPT];
-    bool any_want = false;
-    const uint8_t *sm = sem ? sem + (int64_t)d * hw : nullptr;
+
+    // phase 1: which pixels of the tile are voted on
+    const int l0 = threadIdx.x * GP_PER_THREAD;
+    unsigned wantbits = 0;
+    {
+        const int64_t p0 = tile0 + l0;
+        if (sm && p0 + GP_PER_THREAD <= hw && ((reinterpret_cast<uintptr_t>(sm + p0) & 7) == 0)) {
+            uint2 c8 = *reinterpret_cast<const uint2 *>(sm + p0);
+            unsigned long long bytes = ((unsigned long long)c8.y << 32) | c8.x;
 #pragma unroll
-    for (int j = 0; j < GP_PPT; ++j) {
-        int64_t p = base + (int64_t)j * blockDim.x;
-        bool live = p < hw;
-        // with a semantic map only thing pixels are voted on: every consumer masks the ids by
-        // "class is a thing" (postprocess.py:221, engines.py:280-285), the others are written as 0
-        want[j] = live && (!sm || ((thing_mask >> sm[p]) & 1u));
-        any_want = any_want || want[j];
-        int y = live ? (int)(p / w) : 0, x = live ? (int)(p % w) : 0;
-        float oy = want[j] ? offy[p] : 0.f, ox = want[j] ? offx[p] : 0.f;
-        ly[j] = __fadd_rn((float)(y * step), oy);  // coord + offsets
-        lx[j] = __fadd_rn((float)(x * step), ox);
-        sb[j] = INFINITY;
-        db[j] = dinit;
-        id[j] = want[j] ? idinit : 0;
-    }
-    // whole waves without a thing pixel skip the centre loop (wave-uniform branch)
-    if (__any(any_want)) {
-        for (int k = 0; k < K; ++k) {
-            float2 c = ctr[k];
+            for (int j = 0; j < GP_PER_THREAD; ++j)
+                if ((thing_mask >> ((bytes >> (8 * j)) & 0xff)) & 1u) wantbits |= 1u << j;
+        } else {
 #pragma unroll
-            for (int j = 0; j < GP_PPT; ++j) {
-                float dy = __fsub_rn(c.x, ly[j]);
-                float dx = __fsub_rn(c.y, lx[j]);
-                float s = __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
-                if (want[j] && s < sb[j]) {
-                    sb[j] = s;
-                    float dd = __fsqrt_rn(s);
-                    if (dd < db[j]) { db[j] = dd; id[j] = k + 1; }
-                }
+            for (int j = 0; j < GP_PER_THREAD; ++j) {
+                int64_t p = p0 + j;
+                if (p < hw && (!sm || ((thing_mask >> sm[p]) & 1u))) wantbits |= 1u << j;
             }
         }
     }
+    if (K == 0) wantbits = 0;
 #pragma unroll
-    for (int j = 0; j < GP_PPT; ++j) {
-        int64_t p = base + (int64_t)j * blockDim.x;
-        if (p < hw) out[p] = (uint16_t)id[j];
+    for (int j = 0; j < GP_PER_THREAD; ++j) ids_tile[l0 + j] = 0;
+    int mine = __popc(wantbits);
+    int slot = mine ? atomicAdd(&n_todo, mine) : 0;
+#pragma unroll
+    for (int j = 0; j < GP_PER_THREAD; ++j)
+        if ((wantbits >> j) & 1u) todo[slot++] = (uint16_t)(l0 + j);
+    __syncthreads();
+
+    // phase 2: nearest-centre vote over the compacted list
+    const int n = n_todo;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int l = todo[i];
+        const int64_t p = tile0 + l;
+        const int y = (int)(p / w), x = (int)(p % w);
+        const float ly = __fadd_rn((float)(y * step), offy[p]);  // coord + offsets
+        const float lx = __fadd_rn((float)(x * step), offx[p]);
+        float sb = INFINITY, db = dinit;
+        int id = idinit;
+        for (int k = 0; k < K; ++k) {
+            float2 c = ctr[k];
+            float dy = __fsub_rn(c.x, ly);
+            float dx = __fsub_rn(c.y, lx);
+            float s2 = __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
+            if (s2 < sb) {
+                sb = s2;
+                float dd = __fsqrt_rn(s2);
+                if (dd < db) { db = dd; id = k + 1; }
+            }
+        }
+        ids_tile[l] = (uint16_t)id;
+    }
+    __syncthreads();
+
+    // phase 3: coalesced write-back (8 ids = 16 bytes per lane)
+    {
+        const int64_t p0 = tile0 + l0;
+        if (p0 + GP_PER_THREAD <= hw && ((reinterpret_cast<uintptr_t>(out + p0) & 15) == 0)) {
+            *reinterpret_cast<uint4 *>(out + p0) = *reinterpret_cast<const uint4 *>(&ids_tile[l0]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < GP_PER_THREAD; ++j)
+                if (p0 + j < hw) out[p0 + j] = ids_tile[l0 + j];
+        }
     }
 }
 
@@ -440,7 +485,7 @@ extern "C" int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count
     EMP_REQUIRE((int64_t)h * step < (1 << 24) && (int64_t)w * step < (1 << 24), "group_pixels: coords exceed fp32 integers");
     if (D == 0) return EMP_OK;
     int64_t hw = (int64_t)h * w;
-    int gx = (int)emp_cdiv(hw, 256 * GP_PPT);
+    int gx = (int)emp_cdiv(hw, GP_TILE);
     hipLaunchKernelGGL(group_pixels_kernel, dim3(gx, D), dim3(256), 0, emp_stream(stream), ctr_idx, ctr_count,
                        cap, offsets, h, w, step, sem, thing_mask, out_ids);
     EMP_CHECK_LAUNCH("emp_group_pixels");
