@@ -246,21 +246,22 @@ extern "C" int emp_median_step(const float *const *slices_host, int ks, int64_t 
 
 __device__ __forceinline__ float thresholded(float v, float thr) { return (v > thr) ? v : -1.0f; }
 
+// full k x k test for the rare survivors: no early exit, so the loads of a row are independent and overlap
 __device__ __forceinline__ bool is_window_max(const float *__restrict__ img, int h, int w, int y, int x, float v,
                                               float thr, int k)
 {
     const int pad = k / 2;
+    float m = -INFINITY;
     for (int dy = 0; dy < k; ++dy) {
         int yy = y - pad + dy;
         if (yy < 0 || yy >= h) continue;
         const float *row = img + (int64_t)yy * w;
         for (int dx = 0; dx < k; ++dx) {
             int xx = x - pad + dx;
-            if (xx < 0 || xx >= w) continue;
-            if (thresholded(row[xx], thr) > v) return false;
+            if (xx >= 0 && xx < w) m = fmaxf(m, thresholded(row[xx], thr));
         }
     }
-    return true;
+    return !(m > v);
 }
 
 template <int VEC>
@@ -299,6 +300,9 @@ __global__ __launch_bounds__(256) void find_centers_kernel(const float *__restri
             if (!(c > thr && c > 0.0f)) continue;
             if (need_left && x + j > 0 && thresholded(v[j], thr) > c) continue;
             if (need_right && x + j + 1 < w && thresholded(v[j + 2], thr) > c) continue;
+            // same necessary condition along the column (prunes the ridge of every blob down to its peak)
+            if (need_left && y > 0 && thresholded(img[q + j - w], thr) > c) continue;
+            if (need_right && y + 1 < h && thresholded(img[q + j + w], thr) > c) continue;
             if (is_window_max(img, h, w, y, x + j, c, thr, k)) {
                 int slot = atomicAdd(&out_count[d], 1);
                 if (slot < cap) out_idx[(int64_t)d * cap + slot] = y * w + x + j;
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(256) void group_pixels_kernel(const int32_t *__rest
                                                            int step, const uint8_t *__restrict__ sem,
                                                            uint32_t thing_mask, uint16_t *__restrict__ out_ids)
 {
-    __shared__ float2 ctr[EMP_MAX_CENTERS];
+    extern __shared__ float2 ctr[];  // cap entries
     __shared__ uint16_t todo[GP_TILE];
     __shared__ __attribute__((aligned(16))) uint16_t ids_tile[GP_TILE];
     __shared__ int n_todo;
@@ -486,8 +490,8 @@ extern "C" int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count
     if (D == 0) return EMP_OK;
     int64_t hw = (int64_t)h * w;
     int gx = (int)emp_cdiv(hw, GP_TILE);
-    hipLaunchKernelGGL(group_pixels_kernel, dim3(gx, D), dim3(256), 0, emp_stream(stream), ctr_idx, ctr_count,
-                       cap, offsets, h, w, step, sem, thing_mask, out_ids);
+    hipLaunchKernelGGL(group_pixels_kernel, dim3(gx, D), dim3(256), (size_t)cap * sizeof(float2), emp_stream(stream),
+                       ctr_idx, ctr_count, cap, offsets, h, w, step, sem, thing_mask, out_ids);
     EMP_CHECK_LAUNCH("emp_group_pixels");
     return EMP_OK;
 }
