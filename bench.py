@@ -103,25 +103,22 @@ class Pipeline:
             chk += out['ctr_hmp'].float().sum(dtype=torch.float64) + out['offsets'].float().sum(dtype=torch.float64)
         return prob, chk + prob.sum(dtype=torch.float64)
 
-    def postprocess(self, heads, shape3d):
-        from empanada_amd.inference import filters
-        from empanada_amd.inference import patterns as PA
-        from empanada_amd.inference.postprocess import panoptic_stack
+    def postprocess(self, heads, out_host):
+        """probabilities -> labelled slab in pinned host memory.  Same code path for 1 and N ranks
+        (empanada_amd/inference/sharded.py); with one rank the collectives are no-ops."""
+        from empanada_amd.inference import sharded
         t0 = time.perf_counter()
-        pan, _ = panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'], coarse_boundaries=False, **ENGINE)
+        pan = sharded.sharded_panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'],
+                                             coarse_boundaries=False, **ENGINE)
         torch.cuda.synchronize()
-        st = {'panoptic_stack_incl_wait_for_forward': time.perf_counter() - t0}
-        trackers = PA.track_stack(pan, 'xy', shape3d, [1], ENGINE['thing_list'], ENGINE['label_divisor'], timers=st,
-                                  **MATCH)
         t1 = time.perf_counter()
-        for tr in trackers:
-            filters.remove_small_objects(tr, FILTERS['min_size'])
-            filters.remove_pancakes(tr, FILTERS['min_span'])
-        vol = PA.fill_volume_device(shape3d, trackers)
-        st['filters_and_fill_launch'] = time.perf_counter() - t1
-        self.timers.setdefault('track_host_s', []).append(t1 - t0)
-        self.timers.setdefault('stages', []).append(st)
-        return vol, trackers
+        vol = sharded.sharded_stack_volume(pan, [1], ENGINE['thing_list'], ENGINE['label_divisor'],
+                                           min_size=FILTERS['min_size'], min_span=FILTERS['min_span'], **MATCH)
+        out_host.copy_(vol.view(torch.int32), non_blocking=True)
+        t2 = time.perf_counter()
+        self.timers.setdefault('stages', []).append(
+            {'panoptic_stack_incl_wait_for_forward': t1 - t0, 'runs_chain_fill_launch': t2 - t1})
+        return vol
 
 
 def cpu_baseline(args, vol_u8, heads, n_slices):
@@ -196,12 +193,6 @@ def main():
     host_out = torch.empty((D, S, S), dtype=torch.int32).pin_memory()
     shape3d = (D, S, S)
 
-    def step():
-        prob, chk = pipe.forward(vol)
-        out, trackers = pipe.postprocess(heads, shape3d)
-        host_out.copy_(out.view(torch.int32), non_blocking=True)
-        return chk, trackers
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -213,8 +204,7 @@ def main():
         prob, chk = pipe.forward(vol)
         torch.cuda.synchronize()
         log(f'warmup {i}: forward {time.perf_counter() - t_w:.2f}s')
-        out, trackers = pipe.postprocess(heads, shape3d)
-        host_out.copy_(out.view(torch.int32), non_blocking=True)
+        out = pipe.postprocess(heads, host_out)
         torch.cuda.synchronize()
         log(f'warmup {i}: total {time.perf_counter() - t_w:.2f}s')
     barrier()
@@ -225,8 +215,7 @@ def main():
         ev[3 * k].record()
         prob, chk = pipe.forward(vol)
         ev[3 * k + 1].record()
-        out, trackers = pipe.postprocess(heads, shape3d)
-        host_out.copy_(out.view(torch.int32), non_blocking=True)
+        out = pipe.postprocess(heads, host_out)
         ev[3 * k + 2].record()
     barrier()
     dt = time.perf_counter() - t0
@@ -258,9 +247,8 @@ def main():
                                    f'C=1 fp-forward on every slice + HIP post-processing on planted heads '
                                    f'(ks=7, full-res heads), {n_obj} planted objects per rank',
                        'mode': 'stack', 'slices_per_rank': D, 'batch': args.batch,
-                       'objects_found': int(sum(len(t.instances) for t in trackers))},
+                       'objects_found': int(len(np.unique(host_out.numpy())) - 1)},
             'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'postprocess_to_host': round(float(post_ms), 2),
-                             'host_chain_s': round(float(np.mean(pipe.timers['track_host_s'][-args.steps:])), 4),
                              'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2),
                              'host_stages_s': {k: round(float(np.mean([s[k] for s in pipe.timers['stages'][-args.steps:]])), 4)
                                                for k in pipe.timers['stages'][-1]}},

@@ -54,6 +54,7 @@ SIGNATURES = {
     'emp_vote_work_bytes': (_L, [_L]),
     'emp_vote_ranges': (_I, [_P, _P, _P, _L, _I, _I, _P, _L, _P, _P, _P]),
     'emp_fill_runs_u32': (_I, [_P, _L, _P, _P, _P, _L, _P, _P]),
+    'emp_fill_table_u32': (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     'emp_fill_runs_u8': (_I, [_P, _L, _P, _P, _L, _c.c_uint8, _P]),
 }
 
@@ -338,3 +339,12 @@ def box_pairs(boxes_a, boxes_b=None, src_a=None, src_b=None, upper_only=False):
         if cnt <= cap:
             return out[:cnt]
         cap = cnt
+
+
+def fill_table_u32(vol, table, value_u32, slice0=0):
+    """vol (n_slices, H, W) uint32 device slab <- runs of `table` painted with value_u32[comp] (0 = skip)."""
+    require_gpu()
+    n_slices, H, W = vol.shape
+    call('emp_fill_table_u32', _ptr(vol), H * W, n_slices, int(slice0), _ptr(table.r_start), _ptr(table.r_len),
+         _ptr(table.r_comp), _ptr(table.c_slice), _ptr(value_u32), table.n_runs, stream())
+    return vol

@@ -349,3 +349,41 @@ extern "C" int emp_box_pairs(const int32_t *boxes_a, int64_t na, const int32_t *
     EMP_CHECK_LAUNCH("emp_box_pairs");
     return EMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// fill straight from the run table of one stack: runs of a stack are disjoint, so plain stores suffice.
+// value[comp] == 0 drops the component (filtered instance).  One wave per run.
+__global__ __launch_bounds__(256) void fill_table_kernel(uint32_t *__restrict__ vol, int64_t HW, int slice0,
+                                                         const int32_t *__restrict__ r_start,
+                                                         const int32_t *__restrict__ r_len,
+                                                         const int32_t *__restrict__ r_comp,
+                                                         const int32_t *__restrict__ c_slice,
+                                                         const uint32_t *__restrict__ value, int64_t n_runs,
+                                                         int n_slices)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_runs; r += n_waves) {
+        int comp = r_comp[r];
+        uint32_t v = value[comp];
+        int sl = c_slice[comp] - slice0;
+        if (v == 0 || sl < 0 || sl >= n_slices) continue;
+        uint32_t *dst = vol + (int64_t)sl * HW + r_start[r];
+        for (int i = lane; i < r_len[r]; i += 64) dst[i] = v;
+    }
+}
+
+extern "C" int emp_fill_table_u32(uint32_t *vol, int64_t HW, int n_slices, int slice0, const int32_t *r_start,
+                                  const int32_t *r_len, const int32_t *r_comp, const int32_t *c_slice,
+                                  const uint32_t *value, int64_t n_runs, void *stream)
+{
+    EMP_REQUIRE(n_runs >= 0 && HW > 0 && n_slices >= 0, "fill_table: bad sizes");
+    if (n_runs == 0 || n_slices == 0) return EMP_OK;
+    EMP_REQUIRE(vol && r_start && r_len && r_comp && c_slice && value, "fill_table: null pointer");
+    int grid = emp_grid(n_runs * 64, 256, 8192);
+    hipLaunchKernelGGL(fill_table_kernel, dim3(grid), dim3(256), 0, emp_stream(stream), vol, HW, slice0, r_start, r_len,
+                       r_comp, c_slice, value, n_runs, n_slices);
+    EMP_CHECK_LAUNCH("emp_fill_table_u32");
+    return EMP_OK;
+}

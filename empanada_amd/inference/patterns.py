@@ -35,7 +35,7 @@ __all__ = [
     'update_trackers', 'finish_tracking', 'apply_filters', 'get_axis_trackers_by_class',
     'create_instance_consensus', 'create_semantic_consensus', 'fill_volume', 'fill_panoptic_volume',
     'all_gather', 'forward_multigpu', 'harden_seg', 'get_panoptic_seg',
-    'track_stack', 'fill_volume_device',
+    'track_stack', 'fill_volume_device', 'tables_from_stack', 'chain_from_tables',
 ]
 
 
@@ -339,39 +339,35 @@ class _ClassChain:
         return bwd
 
 
-def track_stack(pan, axis_name, shape3d, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25,
-                return_table=False, timers=None):
-    """Panoptic label stack of one plane (D,H,W uint32, device) -> finished InstanceTrackers, one per label.
-
-    Equivalent to, slice by slice: pan_seg_to_rle_seg(force_connected=True) -> apply_matchers (forward) ->
-    backward_matching -> update_trackers -> finish_tracking (scripts/pdl_inference3d.py:163-198).
-    """
-    import time
-    _t = [time.perf_counter()]
-
-    def _lap(name):
-        if timers is not None:
-            now = time.perf_counter()
-            timers[name] = timers.get(name, 0.0) + now - _t[0]
-            _t[0] = now
-
+def tables_from_stack(pan, labels, thing_list, label_divisor):
+    """GPU half of track_stack: run table + connected components (emp_runs_*) and the overlaps between
+    consecutive slices (emp_runs_overlap_next) of a (D,H,W) uint32 label stack.
+    Returns (RunTable on the device, dict of host tables):
+      c_slice, c_label (cc label), c_area, c_box (n,4), c_cls (class of the original value), trip (k,3)."""
     labels = list(labels)
-    thing_list = list(thing_list)
-    D, H, W = pan.shape
-    table = _hip.extract_runs(pan, label_divisor, [l for l in labels if l in thing_list])
-    _lap('extract_runs')
-    trip = _hip.overlap_next(table, label_divisor).cpu().numpy() if D > 1 and table.n_comp else np.zeros((0, 3), np.int32)
+    D = pan.shape[0]
+    table = _hip.extract_runs(pan, label_divisor, [l for l in labels if l in list(thing_list)])
     nc = table.n_comp
-    c_slice = table.c_slice.cpu().numpy().astype(np.int64)
-    c_label = table.c_label.cpu().numpy()
-    c_area = table.c_area.cpu().numpy()
-    c_box = table.c_box.cpu().numpy()
+    trip = _hip.overlap_next(table, label_divisor).cpu().numpy() if D > 1 and nc else np.zeros((0, 3), np.int32)
     r_val = table.r_val.cpu().numpy()
-    c_cls = (r_val[table.c_first.cpu().numpy()].astype(np.int64) // label_divisor) if nc else np.zeros(0, np.int64)
-    _lap('overlaps_and_tables_to_host')
+    host = {
+        'c_slice': table.c_slice.cpu().numpy().astype(np.int64),
+        'c_label': table.c_label.cpu().numpy(),
+        'c_area': table.c_area.cpu().numpy(),
+        'c_box': table.c_box.cpu().numpy(),
+        'c_cls': (r_val[table.c_first.cpu().numpy()].astype(np.int64) // label_divisor) if nc else np.zeros(0, np.int64),
+        'trip': trip.astype(np.int64),
+    }
+    return table, host
 
-    comp_final = np.zeros(nc, dtype=np.int64)        # final label per component
-    first_seen = {}                                  # class -> (labels, sequence number of first tracker.update)
+
+def chain_from_tables(host, D, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25):
+    """Host half of track_stack: forward + backward label propagation over the component tables of D slices.
+    Returns (comp_final (n,) final label per component, first_seen {class: {label: order of first update}})."""
+    c_slice, c_label, c_area, c_cls, trip = (host[k] for k in ('c_slice', 'c_label', 'c_area', 'c_cls', 'trip'))
+    nc = len(c_slice)
+    comp_final = np.zeros(nc, dtype=np.int64)
+    first_seen = {}
     for l in labels:
         sel = np.flatnonzero(c_cls == l)
         # per slice: components in ascending label order (= dict order of pan_seg_to_rle_seg)
@@ -385,7 +381,7 @@ def track_stack(pan, axis_name, shape3d, labels, thing_list, label_divisor, merg
             slices.append(_Inst(c_label[cs], cs, np.arange(len(cs), dtype=np.int64), c_area[cs]))
         if l in thing_list:
             # overlap triplets of this class, grouped by the slice of the first component
-            ta, tb, tv = trip[:, 0].astype(np.int64), trip[:, 1].astype(np.int64), trip[:, 2].astype(np.int64)
+            ta, tb, tv = trip[:, 0], trip[:, 1], trip[:, 2]
             m = c_cls[ta] == l if len(ta) else np.zeros(0, dtype=bool)
             ta, tb, tv = ta[m], tb[m], tv[m]
             o = np.argsort(c_slice[ta], kind='stable') if len(ta) else np.zeros(0, np.int64)
@@ -417,10 +413,34 @@ def track_stack(pan, axis_name, shape3d, labels, thing_list, label_divisor, merg
                         seen.add(lab)
                         lab_seq.append(lab)
         first_seen[l] = {lab: i for i, lab in enumerate(lab_seq)}
+    return comp_final, first_seen
 
+
+def track_stack(pan, axis_name, shape3d, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25,
+                return_table=False, timers=None):
+    """Panoptic label stack of one plane (D,H,W uint32, device) -> finished InstanceTrackers, one per label.
+
+    Equivalent to, slice by slice: pan_seg_to_rle_seg(force_connected=True) -> apply_matchers (forward) ->
+    backward_matching -> update_trackers -> finish_tracking (scripts/pdl_inference3d.py:163-198).
+    """
+    import time
+    _t = [time.perf_counter()]
+
+    def _lap(name):
+        if timers is not None:
+            now = time.perf_counter()
+            timers[name] = timers.get(name, 0.0) + now - _t[0]
+            _t[0] = now
+
+    labels = list(labels)
+    thing_list = list(thing_list)
+    D = pan.shape[0]
+    table, host = tables_from_stack(pan, labels, thing_list, label_divisor)
+    _lap('runs_cc_overlaps_to_host')
+    comp_final, first_seen = chain_from_tables(host, D, labels, thing_list, label_divisor, merge_iou_thr, merge_ioa_thr)
     _lap('matching_chain')
-    trackers = _assemble_trackers(table, comp_final, c_slice, c_cls, c_box, first_seen, axis_name, shape3d, labels,
-                                  label_divisor)
+    trackers = _assemble_trackers(table, comp_final, host['c_slice'], host['c_cls'], host['c_box'], first_seen,
+                                  axis_name, shape3d, labels, label_divisor)
     _lap('assemble_trackers')
     return (trackers, table, comp_final) if return_table else trackers
 

@@ -204,6 +204,13 @@ int emp_fill_runs_u32(uint32_t *vol, int64_t n_vox, const int64_t *starts, const
                       const int32_t *order, int64_t n_runs, const uint32_t *ids, void *stream);
 int emp_fill_runs_u8(uint8_t *vol, int64_t n_vox, const int64_t *starts, const int64_t *lens,
                      int64_t n_runs, uint8_t value, void *stream);
+/* Fill a slab (n_slices, HW) of an xy-stack volume straight from the run table of emp_runs_extract /
+ * emp_runs_label: run i paints value[r_comp[i]] at slice c_slice[r_comp[i]] - slice0 (runs whose value
+ * is 0 or whose slice falls outside the slab are skipped).  Runs of one stack never overlap.
+ * replaces update_trackers + numpy_fill_instances for stack mode (scripts/pdl_inference3d.py:190-233). */
+int emp_fill_table_u32(uint32_t *vol, int64_t HW, int n_slices, int slice0, const int32_t *r_start,
+                       const int32_t *r_len, const int32_t *r_comp, const int32_t *c_slice,
+                       const uint32_t *value, int64_t n_runs, void *stream);
 
 #ifdef __cplusplus
 }

@@ -271,3 +271,27 @@ def test_model_forward_matches_cpu_within_tolerance():
         scale = float(ref[k].abs().max())
         err = float((out[k].float().cpu() - ref[k]).abs().max())
         assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (k, err, scale)
+
+
+def test_sharded_path_world1_equals_tracker_path():
+    """bench.py's path (sharded.py with one rank: tables -> chain -> filters on tables -> fill from the run
+    table) paints exactly the volume of track_stack -> filters -> fill_volume_device."""
+    from empanada_amd.inference import filters, sharded
+    from empanada_amd.inference import patterns as PA
+    from empanada_amd.inference.postprocess import panoptic_stack
+    lab, cls = SY.planted_labels((24, 96, 128), fill=0.2, rmin=4, rmax=12, seed=8)
+    heads = SY.planted_heads(lab, cls, 'xy', seed=4)
+    kw = dict(thing_list=[1], label_divisor=20000, stuff_area=64, void_label=0, nms_threshold=0.1, nms_kernel=7,
+              confidence_thr=0.3, median_kernel_size=7)
+    sem, ctr, off = heads['sem'].cuda(), heads['ctr_hmp'].cuda(), heads['offsets'].cuda()
+    pan, _ = panoptic_stack(sem, ctr, off, coarse_boundaries=False, **kw)
+    pan2 = sharded.sharded_panoptic_stack(sem, ctr, off, coarse_boundaries=False, **kw)
+    np.testing.assert_array_equal(pan.cpu().numpy(), pan2.cpu().numpy())
+    trs = PA.track_stack(pan, 'xy', lab.shape, [1], [1], 20000, 0.25, 0.25)
+    for tr in trs:
+        filters.remove_small_objects(tr, 300)
+        filters.remove_pancakes(tr, 4)
+    exp = PA.fill_volume_device(lab.shape, trs).cpu().numpy()
+    got = sharded.sharded_stack_volume(pan2, [1], [1], 20000, 0.25, 0.25, min_size=300, min_span=4).cpu().numpy()
+    assert exp.max() > 0 and len(np.unique(exp)) > 5
+    np.testing.assert_array_equal(got, exp)

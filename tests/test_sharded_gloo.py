@@ -1,0 +1,166 @@
+"""CPU, world_size 2, gloo: the host half of the slice-sharded multi-GPU path
+(empanada_amd/inference/sharded.py: merge of per-rank component tables with a one-slice halo, the global
+label-propagation chain on rank 0, the broadcast of final labels) gives exactly the labels of the
+single-rank chain -- which tests/test_pipeline_gpu.py pins to the reference."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from empanada_amd import synthetic as SY
+from empanada_amd.inference import sharded
+from empanada_amd.inference.patterns import chain_from_tables
+from oracle import rle_seg as OS
+
+DIV = 1000
+
+
+def cpu_tables(pan, labels, thing_list):
+    """numpy twin of patterns.tables_from_stack (which needs the GPU), built on the oracle's CC."""
+    D, H, W = pan.shape
+    c_slice, c_label, c_area, c_box, c_cls = [], [], [], [], []
+    comp_maps = np.full((D, H * W), -1, dtype=np.int64)
+    for d in range(D):
+        firsts = []
+        for l in labels:
+            seg = np.where((pan[d] >= l * DIV) & (pan[d] < (l + 1) * DIV), pan[d], 0)
+            if l in thing_list:
+                cc = OS.connected_components(seg)
+                ids = [(k, l * DIV + k) for k in range(1, int(cc.max()) + 1)]
+                lab_img = cc
+            else:
+                vals = [int(v) for v in np.unique(seg) if v]
+                ids = [(v, v) for v in vals]
+                lab_img = seg
+            for k, lab in ids:
+                m = lab_img == k
+                flat = np.flatnonzero(m.ravel())
+                ys, xs = np.nonzero(m)
+                firsts.append((int(flat[0]), l, lab, int(m.sum()), (ys.min(), xs.min(), ys.max() + 1, xs.max() + 1), flat))
+        firsts.sort(key=lambda t: t[0])                # component order of the run table: first pixel, raster
+        for _, l, lab, area, box, flat in firsts:
+            comp_maps[d, flat] = len(c_slice)
+            c_slice.append(d); c_label.append(lab); c_area.append(area); c_box.append(box); c_cls.append(l)
+    c_cls = np.array(c_cls, dtype=np.int64)
+    trip = {}
+    for d in range(D - 1):
+        a, b = comp_maps[d], comp_maps[d + 1]
+        m = (a >= 0) & (b >= 0)
+        m[m] &= c_cls[a[m]] == c_cls[b[m]]
+        for x, y in zip(a[m], b[m]):
+            trip[(int(x), int(y))] = trip.get((int(x), int(y)), 0) + 1
+    trip = np.array([(a, b, n) for (a, b), n in trip.items()], dtype=np.int64).reshape(-1, 3)
+    host = dict(c_slice=np.array(c_slice, dtype=np.int64), c_label=np.array(c_label, dtype=np.int64),
+                c_area=np.array(c_area, dtype=np.int64), c_box=np.array(c_box, dtype=np.int32).reshape(-1, 4),
+                c_cls=c_cls, trip=trip)
+    return host, comp_maps
+
+
+def make_stack(seed=0, shape=(14, 40, 48)):
+    lab, cls = SY.planted_labels(shape, fill=0.25, rmin=4, rmax=9, seed=seed, n_classes=2)
+    pan = np.zeros(shape, dtype=np.int64)
+    rng = np.random.default_rng(seed)
+    for i in range(1, len(cls)):
+        # slice-dependent ids so that matching has real work; class 2 = stuff (id 0)
+        pan[lab == i] = 1 * DIV + 1 + (i * 7) % 50 if cls[i] == 1 else 2 * DIV
+    pan[:, ::9, :] = 0                                  # split objects into several components
+    return pan
+
+
+def paint(comp_maps, final):
+    out = np.zeros(comp_maps.shape, dtype=np.int64)
+    m = comp_maps >= 0
+    out[m] = final[comp_maps[m]]
+    return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, bounds, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        pan = make_stack()
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        ext = pan[lo:hi + 1] if rank + 1 < world else pan[lo:hi]
+        host, maps = cpu_tables(ext, [1, 2], [1])
+        final = sharded.gather_tables_and_chain(host, hi - lo, [1, 2], [1], DIV, 0.25, 0.25, min_size=60, min_span=3)
+        q.put((rank, paint(maps[:hi - lo], final)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('split', [(7, 7), (5, 9)])
+def test_two_rank_chain_equals_single_rank(split):
+    pan = make_stack()
+    host, maps = cpu_tables(pan, [1, 2], [1])
+    final, _ = chain_from_tables(host, pan.shape[0], [1, 2], [1], DIV, 0.25, 0.25)
+    final = sharded.filter_labels(host, final, min_size=60, min_span=3)
+    expected = paint(maps, final)
+    assert len(np.unique(expected)) > 4, "the synthetic stack should keep several instances"
+    assert (expected > 0).sum() < (pan > 0).sum(), "the filters should remove something"
+
+    bounds = np.concatenate([[0], np.cumsum(split)])
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bounds, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(np.concatenate([got[0], got[1]]), expected)
+
+
+def test_shard_bounds():
+    np.testing.assert_array_equal(sharded.shard_bounds(10, 4), [0, 3, 6, 8, 10])
+    np.testing.assert_array_equal(sharded.shard_bounds(8, 8), np.arange(9))
+
+
+def test_filter_labels_matches_tracker_filters():
+    """filters evaluated on tables == remove_small_objects / remove_pancakes on assembled trackers (oracle)."""
+    pan = make_stack(seed=3)
+    host, maps = cpu_tables(pan, [1, 2], [1])
+    final, _ = chain_from_tables(host, pan.shape[0], [1, 2], [1], DIV, 0.25, 0.25)
+    kept = sharded.filter_labels(host, final, min_size=80, min_span=4)
+    vol = paint(maps, final).reshape(pan.shape)
+    exp = vol.copy()
+    for lab in np.unique(vol):
+        if lab == 0:
+            continue
+        zz, yy, xx = np.nonzero(vol == lab)
+        spans = [zz.max() - zz.min() + 1, yy.max() - yy.min() + 1, xx.max() - xx.min() + 1]
+        if len(zz) < 80 or min(spans) < 4:
+            exp[vol == lab] = 0
+    np.testing.assert_array_equal(paint(maps, kept).reshape(pan.shape), exp)
+
+
+def test_host_chain_against_reference_goldens():
+    """CPU: chain_from_tables (the host half of track_stack) on the reference's own per-slice panoptic
+    stacks reproduces the reference's labels after forward + backward matching (tests/golden/pipeline.npz)."""
+    from conftest import load_golden
+    g = load_golden('pipeline')
+    global DIV
+    for i in range(int(g['n'])):
+        C = int(g[f'p{i}_par'][0])
+        thing = [1] if C == 1 else list(range(1, C))
+        labels = [1] if C == 1 else list(range(1, C + 1))
+        for name in ('xy', 'xz', 'yz'):
+            pans = g[f'p{i}_{name}_pan'].astype(np.int64)
+            host, maps = cpu_tables(pans, labels, thing)
+            final, _ = chain_from_tables(host, pans.shape[0], labels, thing, DIV, 0.25, 0.25)
+            np.testing.assert_array_equal(paint(maps, final).reshape(pans.shape), g[f'p{i}_{name}_bwd'],
+                                          err_msg=f'{i} {name}')
