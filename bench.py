@@ -129,6 +129,8 @@ def cpu_baseline(args, vol_u8, heads, n_slices):
     from oracle import rle_ops as OR
     from oracle import rle_seg as OS
     n = min(n_slices, vol_u8.shape[0])
+    cores = min(16, os.cpu_count() or 1)          # the GPU box grants a 16-core share per GPU
+    torch.set_num_threads(cores)
     model = synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)).eval()
     x = vol_u8[:n].cpu().float().unsqueeze(1)
     x = (x - 255 * NORM['mean']) / (255 * NORM['std'])
@@ -158,7 +160,7 @@ def cpu_baseline(args, vol_u8, heads, n_slices):
         OR.numpy_fill_instances(out, tr.instances)
     dt = time.perf_counter() - t0
     vox = float(np.prod(shape))
-    return {'value': round(vox / dt / 1e6, 4), 'unit': 'Mvox/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    return {'value': round(vox / dt / 1e6, 4), 'unit': 'Mvox/s', 'cores': cores, 'kind': 'port',
             'sample': f'first {len(pans)} of {vol_u8.shape[0]} slices ({shape[1]}x{shape[2]}), same heads; '
                       f'conv {t_conv:.1f}s of {dt:.1f}s', 'objects': int(sum(len(t.instances) for t in trs))}
 
