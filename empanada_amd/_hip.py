@@ -33,6 +33,7 @@ SIGNATURES = {
     'emp_version': (_I, []),
     'emp_last_error': (_c.c_char_p, []),
     'emp_device_count': (_I, []),
+    'emp_bn_act_nhwc': (_I, [_P, _P, _P, _P, _I, _L, _I, _P, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
@@ -348,3 +349,14 @@ def fill_table_u32(vol, table, value_u32, slice0=0):
     call('emp_fill_table_u32', _ptr(vol), H * W, n_slices, int(slice0), _ptr(table.r_start), _ptr(table.r_len),
          _ptr(table.r_comp), _ptr(table.c_slice), _ptr(value_u32), table.n_runs, stream())
     return vol
+
+
+def bn_act_nhwc_(x, scale, shift, residual=None, relu=True):
+    """in place on x (N,C,H,W fp32 in channels_last memory): relu?(x*scale[c] + shift[c] (+ residual))."""
+    N, C, H, W = x.shape
+    assert x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32
+    if residual is not None:
+        assert residual.shape == x.shape and residual.is_contiguous(memory_format=torch.channels_last)
+    call('emp_bn_act_nhwc', x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+         residual.data_ptr() if residual is not None else None, int(bool(relu)), N * H * W, C, x.data_ptr(), stream())
+    return x

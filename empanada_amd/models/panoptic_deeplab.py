@@ -51,6 +51,35 @@ def _sepconv_bn_act(nin, nout, k):
     return nn.Sequential(SeparableConv2d(nin, nout, k, 1, bias=False), nn.BatchNorm2d(nout), nn.ReLU(inplace=True))
 
 
+def _bn_affine(bn):
+    """eval-mode BatchNorm as a per-channel affine map: (scale, shift) fp32"""
+    scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)).contiguous()
+    shift = (bn.bias.detach().float() - bn.running_mean.detach().float() * scale).contiguous()
+    return scale, shift
+
+
+class FusedBNAct(nn.Module):
+    """Inference-only stand-in for BatchNorm2d(+ReLU): one in-place HIP pass (emp_bn_act_nhwc) over the NHWC
+    conv output instead of separate MIOpen batch-norm and ReLU kernels."""
+
+    def __init__(self, bn, relu):
+        super().__init__()
+        scale, shift = _bn_affine(bn)
+        self.register_buffer('scale', scale, persistent=False)
+        self.register_buffer('shift', shift, persistent=False)
+        self.relu = relu
+
+    def forward(self, x, residual=None):
+        from .. import _hip
+        if not (x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0):
+            raise RuntimeError("FusedBNAct needs fp32 CUDA activations with C % 4 == 0")
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+            residual = residual.contiguous(memory_format=torch.channels_last)
+        return _hip.bn_act_nhwc_(x, self.scale, self.shift, residual, self.relu)
+
+
 class _Basic(nn.Module):
     expansion = 1
 
@@ -65,6 +94,9 @@ class _Basic(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
+        if isinstance(self.bn1, FusedBNAct):
+            out = self.bn1(self.conv1(x))
+            return self.bn2(self.conv2(out), idt)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         return self.relu(out + idt)
@@ -87,6 +119,9 @@ class _Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
+        if isinstance(self.bn1, FusedBNAct):
+            out = self.bn2(self.conv2(self.bn1(self.conv1(x))))
+            return self.bn3(self.conv3(out), idt)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
@@ -133,7 +168,10 @@ class ResNetEncoder(nn.Module):
         return nn.Sequential(*mods)
 
     def forward(self, x):
-        p1 = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        if isinstance(self.bn1, FusedBNAct):
+            p1 = self.maxpool(self.bn1(self.conv1(x)))
+        else:
+            p1 = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         p2 = self.layer1(p1)
         p3 = self.layer2(p2)
         p4 = self.layer3(p3)
@@ -277,12 +315,38 @@ def synthesize_weights(model, scale_bn=True):
     return model
 
 
-def prepare_for_inference(model, device='cuda', dtype=torch.float32, channels_last=True):
-    """eval(), move to the GPU, NHWC memory format (MIOpen's fast layout on gfx950) and optional bf16/fp16
-    weights.  fp32 is the default so that logits stay within the stated tolerance of the CPU reference."""
+def fuse_bn_act(model):
+    """Swap every eval-mode BatchNorm2d (and the ReLU / residual add that follows it) for FusedBNAct.
+    Patterns: ResNet blocks and stem (handled in their forward), Sequential[..., BatchNorm2d, ReLU, ...]."""
+    for m in model.modules():
+        if isinstance(m, (_Basic, _Bottleneck)):
+            last = 'bn2' if isinstance(m, _Basic) else 'bn3'
+            for name in ('bn1', 'bn2', 'bn3'):
+                if hasattr(m, name) and isinstance(getattr(m, name), nn.BatchNorm2d):
+                    setattr(m, name, FusedBNAct(getattr(m, name), relu=True))
+            assert isinstance(getattr(m, last), FusedBNAct)
+        elif isinstance(m, ResNetEncoder):
+            m.bn1 = FusedBNAct(m.bn1, relu=True)
+        elif isinstance(m, nn.Sequential):
+            for i, child in enumerate(list(m)):
+                if isinstance(child, nn.BatchNorm2d) and child.num_features % 4 == 0:
+                    nxt = m[i + 1] if i + 1 < len(m) else None
+                    relu = isinstance(nxt, nn.ReLU)
+                    m[i] = FusedBNAct(child, relu=relu)
+                    if relu:
+                        m[i + 1] = nn.Identity()
+    return model
+
+
+def prepare_for_inference(model, device='cuda', dtype=torch.float32, channels_last=True, fuse=True):
+    """eval(), move to the GPU, NHWC memory format (MIOpen's fast layout on gfx950), optional bf16/fp16
+    weights, and (fp32 NHWC only) the fused BatchNorm+ReLU(+residual) epilogue kernel.  fp32 is the default so
+    that logits stay within the stated tolerance of the CPU reference."""
     model = model.eval().to(device)
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
     if dtype != torch.float32:
         model = model.to(dtype)
+    elif fuse and channels_last and torch.device(device).type == 'cuda':
+        model = fuse_bn_act(model)
     return model

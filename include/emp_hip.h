@@ -42,6 +42,16 @@ const char *emp_last_error(void);
 /* Number of visible HIP devices (does not create a context). */
 int emp_device_count(void);
 
+/* ---- D1 epilogue: fused BatchNorm(eval) + residual + ReLU on NHWC fp32 activations -----------------
+ * replaces the elementwise tail of every conv block of the dense path:
+ *          Bottleneck / BasicBlock forward         empanada/models/encoders/resnet.py:66-82,110-128
+ *          conv_bn_act / separable_conv_bn_act     empanada/models/blocks.py:121-171
+ * out[p, c] = act(x[p, c] * scale[c] + shift[c] (+ residual[p, c])), act = ReLU if relu != 0.
+ * scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (precomputed by the host).
+ * x, residual, out: (n_pixels, C) fp32 (NHWC memory), C % 4 == 0, 16-byte aligned; out may alias x.    */
+int emp_bn_act_nhwc(const float *x, const float *scale, const float *shift, const float *residual,
+                    int relu, int64_t n_pixels, int C, float *out, void *stream);
+
 /* ---- P1 + P2: recursive median over a resident stack, fused with hardening ----------------
  * replaces _MedianQueue.get_next/get_median/end   empanada/inference/engines.py:47-90
  *          _harden_seg / harden_seg               engines.py:114-121, inference/patterns.py:242-251
