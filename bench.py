@@ -57,6 +57,9 @@ def parse():
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--cpu-slices', type=int, default=12, help='slices of the same workload for the CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', default='stack', choices=['stack', 'orthoplane'],
+                    help='stack = BASELINE configs[1] (xy only); orthoplane = configs[2] (xy/xz/yz + consensus, '
+                         'cubic volume of side --size, single GPU)')
     return ap.parse_args()
 
 
@@ -121,6 +124,93 @@ class Pipeline:
         return vol
 
 
+def build_inputs_ortho(S, device):
+    from empanada_amd import synthetic as SY
+    shape = (S, S, S)
+    vol = torch.from_numpy(SY.em_volume(shape, seed=1234)).to(device)
+    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321)
+    heads = {}
+    for axis in ('xy', 'xz', 'yz'):
+        parts = {'sem': [], 'ctr_hmp': [], 'offsets': []}
+        for s in range(0, S, 64):
+            h = SY.planted_heads(lab, cls, axis, device=device, slices=slice(s, min(S, s + 64)), seed=99 + s)
+            for k in parts:
+                parts[k].append(h[k])
+        heads[axis] = {k: torch.cat(v, dim=0).contiguous() for k, v in parts.items()}
+    return vol, heads, int(cls.shape[0] - 1)
+
+
+def orthoplane_step(pipe, vol, heads, host_out, stages):
+    """One pass of BASELINE configs[2]: three stacks (xy, xz, yz) -> trackers -> filters -> instance consensus
+    -> filters -> labelled volume in pinned host memory (scripts/pdl_inference3d.py:110-233 in orthoplane mode)."""
+    from empanada_amd.inference import filters
+    from empanada_amd.inference import patterns as PA
+    from empanada_amd.inference.postprocess import panoptic_stack
+    shape3d = tuple(vol.shape)
+    trackers = {}
+    chk = 0
+    for axis, perm in (('xy', (0, 1, 2)), ('xz', (1, 0, 2)), ('yz', (2, 0, 1))):
+        t0 = time.perf_counter()
+        stack = vol.permute(*perm).contiguous()
+        prob, c = pipe.forward(stack)
+        chk = chk + c
+        h = heads[axis]
+        pan, _ = panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False, **ENGINE)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        trs = PA.track_stack(pan, axis, shape3d, [1], ENGINE['thing_list'], ENGINE['label_divisor'], **MATCH)
+        for tr in trs:
+            filters.remove_small_objects(tr, FILTERS['min_size'])
+            filters.remove_pancakes(tr, FILTERS['min_span'])
+        trackers[axis] = trs
+        t2 = time.perf_counter()
+        stages[f'{axis}_forward_and_pixels'] = stages.get(f'{axis}_forward_and_pixels', 0) + t1 - t0
+        stages[f'{axis}_tracking'] = stages.get(f'{axis}_tracking', 0) + t2 - t1
+    t0 = time.perf_counter()
+    con = PA.create_instance_consensus(PA.get_axis_trackers_by_class(trackers, 1), 2, 0.75, False)
+    filters.remove_small_objects(con, FILTERS['min_size'])
+    filters.remove_pancakes(con, FILTERS['min_span'])
+    t1 = time.perf_counter()
+    out = PA.fill_volume_device(shape3d, [con])
+    host_out.copy_(out.view(torch.int32), non_blocking=True)
+    torch.cuda.synchronize()
+    stages['consensus'] = stages.get('consensus', 0) + t1 - t0
+    stages['fill_to_host'] = stages.get('fill_to_host', 0) + time.perf_counter() - t1
+    return chk, len(con.instances)
+
+
+def main_orthoplane(args, device):
+    S = args.size
+    log(f'orthoplane: building inputs {S}^3')
+    vol, heads, n_obj = build_inputs_ortho(S, device)
+    log(f'inputs ready ({n_obj} planted objects)')
+    pipe = Pipeline(args, device)
+    host_out = torch.empty((S, S, S), dtype=torch.int32).pin_memory()
+    for i in range(args.warmup):
+        orthoplane_step(pipe, vol, heads, host_out, {})
+        log(f'warmup {i} done')
+    torch.cuda.synchronize()
+    stages = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        chk, n_found = orthoplane_step(pipe, vol, heads, host_out, stages)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {
+        'metric': 'Mvox/s end-to-end 3D panoptic inference (incl. consensus); PQ vs CPU ref',
+        'value': round(float(S) ** 3 * args.steps / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else args.dtype,
+        'data': 'synthetic',
+        'config': {'workload': f'orthoplane (xy/xz/yz) inference + instance consensus, {S}^3 uint8 volume, '
+                               f'PanopticDeepLab/ResNet-50 C=1 forward on every slice of every plane + HIP '
+                               f'post-processing on planted heads, {n_obj} planted objects',
+                   'mode': 'orthoplane', 'objects_found': int(n_found)},
+        'stages_s_per_step': {k: round(v / args.steps, 4) for k, v in stages.items()},
+    }
+    print(json.dumps(res), flush=True)
+
+
 def cpu_baseline(args, vol_u8, heads, n_slices):
     """The oracle chain (CPU restatement of the reference) + torch-CPU forward on a bounded sample of the
     same workload: the first n_slices slices.  kind = 'port'."""
@@ -160,9 +250,20 @@ def cpu_baseline(args, vol_u8, heads, n_slices):
         OR.numpy_fill_instances(out, tr.instances)
     dt = time.perf_counter() - t0
     vox = float(np.prod(shape))
+    # the HIP path on exactly the same sample -> PQ against the CPU result and identity of the instance ids
+    from empanada_amd.evaluation import volume_pq
+    from empanada_amd.inference import sharded
+    sub = {k: heads[k][:n].contiguous() for k in heads}
+    pan = sharded.sharded_panoptic_stack(sub['sem'], sub['ctr_hmp'], sub['offsets'], coarse_boundaries=False, **ENGINE)
+    got = sharded.sharded_stack_volume(pan, [1], ENGINE['thing_list'], ENGINE['label_divisor'],
+                                       min_size=FILTERS['min_size'], min_span=FILTERS['min_span'], **MATCH)
+    got = got.view(torch.int32).cpu().numpy().astype(np.uint32)
+    pq, n_gt, n_pred, n_match = volume_pq(out, got)
     return {'value': round(vox / dt / 1e6, 4), 'unit': 'Mvox/s', 'cores': cores, 'kind': 'port',
             'sample': f'first {len(pans)} of {vol_u8.shape[0]} slices ({shape[1]}x{shape[2]}), same heads; '
-                      f'conv {t_conv:.1f}s of {dt:.1f}s', 'objects': int(sum(len(t.instances) for t in trs))}
+                      f'conv {t_conv:.1f}s of {dt:.1f}s', 'objects': int(sum(len(t.instances) for t in trs)),
+            'pq_vs_cpu_ref': round(pq, 6), 'ids_identical': bool(np.array_equal(out, got)),
+            'instances_cpu_gpu_matched': [n_gt, n_pred, n_match]}
 
 
 def log(msg):
@@ -187,6 +288,9 @@ def main():
     _hip.load()
     torch.backends.cudnn.benchmark = True
 
+    if args.mode == 'orthoplane':
+        assert world == 1, "orthoplane bench mode is single-GPU this round"
+        return main_orthoplane(args, device)
     D, S = args.depth, args.size
     log(f'building inputs {D}x{S}x{S}')
     vol, heads, n_obj = build_inputs(D, S, device, seed_offset=rank)
