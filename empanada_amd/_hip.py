@@ -56,6 +56,7 @@ SIGNATURES = {
     'emp_vote_ranges': (_I, [_P, _P, _P, _L, _I, _I, _P, _L, _P, _P, _P]),
     'emp_fill_runs_u32': (_I, [_P, _L, _P, _P, _P, _L, _P, _P]),
     'emp_fill_table_u32': (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
+    'emp_scatter_yz_u32': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     'emp_fill_runs_u8': (_I, [_P, _L, _P, _P, _L, _c.c_uint8, _P]),
 }
 
@@ -360,3 +361,30 @@ def bn_act_nhwc_(x, scale, shift, residual=None, relu=True):
     call('emp_bn_act_nhwc', x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
          residual.data_ptr() if residual is not None else None, int(bool(relu)), N * H * W, C, x.data_ptr(), stream())
     return x
+
+
+def yz_runs_along_x(table, value_u32, shape3d):
+    """yz stack run table + per-component value -> 3D runs along x of the dense (Z,Y,X) labelling:
+    (start3d int64, len int64, value int64) numpy arrays in raster order (emp_scatter_yz_u32 + row-run kernels)."""
+    require_gpu()
+    Z, Y, X = shape3d
+    dev = table.r_start.device
+    vol = torch.zeros((Z, Y, X), dtype=torch.int32, device=dev).view(torch.uint32)
+    call('emp_scatter_yz_u32', _ptr(vol), Z, Y, X, _ptr(table.r_start), _ptr(table.r_len), _ptr(table.r_comp),
+         _ptr(table.c_slice), _ptr(value_u32), table.n_runs, stream())
+    rows = torch.empty((Z * Y,), dtype=torch.int32, device=dev)
+    call('emp_runs_count', _ptr(vol), Z, Y, X, _ptr(rows), stream())
+    offs = exclusive_scan_i32(rows)
+    n = int(offs[-1].item())
+    r_start = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    r_len = torch.empty_like(r_start)
+    r_val = torch.empty((max(n, 1),), dtype=torch.uint32, device=dev)
+    call('emp_runs_extract', _ptr(vol), Z, Y, X, _ptr(offs), _ptr(r_start), _ptr(r_len), _ptr(r_val), stream())
+    import numpy as np
+    offs_h = offs.cpu().numpy().astype(np.int64)
+    st = r_start[:n].cpu().numpy().astype(np.int64)
+    ln = r_len[:n].cpu().numpy().astype(np.int64)
+    val = r_val[:n].cpu().numpy().astype(np.int64)
+    row = np.searchsorted(offs_h, np.arange(n), side='right') - 1          # row = z * Y + y
+    z = row // Y
+    return st + z * (Y * X), ln, val

@@ -387,3 +387,42 @@ extern "C" int emp_fill_table_u32(uint32_t *vol, int64_t HW, int n_slices, int s
     EMP_CHECK_LAUNCH("emp_fill_table_u32");
     return EMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// T1 (yz plane): scatter the runs of a yz stack (slices along x; each slice is a (Z, Y) image) into a dense
+// (Z, Y, X) label volume: voxel (z, y, t) of run (slice t, pixels p..p+len) gets value[comp].  The 3D RLE
+// the reference builds by decoding every pixel, sorting and re-encoding (tracker.py:83-88,110-113) is then
+// read off the volume with the row-run kernels (runs along x).
+__global__ __launch_bounds__(256) void scatter_yz_kernel(uint32_t *__restrict__ vol, int Y, int X,
+                                                         const int32_t *__restrict__ r_start,
+                                                         const int32_t *__restrict__ r_len,
+                                                         const int32_t *__restrict__ r_comp,
+                                                         const int32_t *__restrict__ c_slice,
+                                                         const uint32_t *__restrict__ value, int64_t n_runs)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_runs; r += n_waves) {
+        int comp = r_comp[r];
+        uint32_t v = value[comp];
+        if (v == 0) continue;
+        const int64_t t = c_slice[comp];
+        const int64_t p0 = r_start[r];
+        for (int i = lane; i < r_len[r]; i += 64) vol[(p0 + i) * X + t] = v;   // (z*Y + y) * X + t
+    }
+}
+
+extern "C" int emp_scatter_yz_u32(uint32_t *vol, int Z, int Y, int X, const int32_t *r_start, const int32_t *r_len,
+                                  const int32_t *r_comp, const int32_t *c_slice, const uint32_t *value,
+                                  int64_t n_runs, void *stream)
+{
+    EMP_REQUIRE(n_runs >= 0 && Z > 0 && Y > 0 && X > 0, "scatter_yz: bad sizes");
+    if (n_runs == 0) return EMP_OK;
+    EMP_REQUIRE(vol && r_start && r_len && r_comp && c_slice && value, "scatter_yz: null pointer");
+    int grid = emp_grid(n_runs * 64, 256, 8192);
+    hipLaunchKernelGGL(scatter_yz_kernel, dim3(grid), dim3(256), 0, emp_stream(stream), vol, Y, X, r_start, r_len,
+                       r_comp, c_slice, value, n_runs);
+    EMP_CHECK_LAUNCH("emp_scatter_yz_u32");
+    return EMP_OK;
+}

@@ -479,18 +479,19 @@ def _assemble_trackers(table, comp_final, c_slice, c_cls, c_box, first_seen, axi
             elif axis_name == 'xz':           # 2D plane (Z, X): only the run START is mapped (tracker.py:78-82)
                 st3 = (st // W) * (Y * X) + sl * X + (st % W)
                 ln3 = ln
-            else:                              # 2D plane (Z, Y): pixels become unit runs, sorted + re-encoded
-                rep = np.repeat(np.arange(len(st)), ln)
-                pix = st[rep] + (np.arange(len(rep)) - np.repeat(np.cumsum(ln) - ln, ln))
-                vox = (pix // W) * (Y * X) + (pix % W) * X + sl[rep]
-                vlab = lb[rep]
-                o2 = np.lexsort((vox, vlab))
-                vox, vlab = vox[o2], vlab[o2]
-                b2 = np.ones(len(vox), dtype=bool)
-                b2[1:] = (vlab[1:] != vlab[:-1]) | (vox[1:] != vox[:-1] + 1)
+            else:
+                # 2D plane (Z, Y), slices along x: the reference decodes every pixel to a unit run and, at finish(),
+                # sorts and re-encodes them (tracker.py:83-88,110-113) -- i.e. the RLE along x of the dense labelling.
+                # The GPU scatters the labels into a (Z, Y, X) volume and reads the runs back with the row-run kernels.
+                cval = np.where(c_cls == l, comp_final, 0)
+                st3, ln3, lb = _hip.yz_runs_along_x(table, _hip.np_to_dev_u32(cval), shape3d)
+                o2 = np.argsort(lb, kind='stable')                                       # by label, voxel order inside
+                st3, ln3, lb = st3[o2], ln3[o2], lb[o2]
+                b2 = np.ones(len(st3), dtype=bool)
+                b2[1:] = (lb[1:] != lb[:-1]) | (st3[1:] != st3[:-1] + ln3[:-1])          # runs touching across row ends merge
                 s2 = np.flatnonzero(b2)
-                st3, lb = vox[s2], vlab[s2]
-                ln3 = np.diff(np.concatenate([s2, [len(vox)]]))
+                ln3 = np.add.reduceat(ln3, s2) if len(s2) else ln3
+                st3, lb = st3[s2], lb[s2]
             cuts = np.flatnonzero(np.diff(lb)) + 1
             lab_vals = lb[np.concatenate([[0], cuts])]
             st_parts = np.split(st3, cuts)

@@ -222,6 +222,16 @@ int emp_fill_table_u32(uint32_t *vol, int64_t HW, int n_slices, int slice0, cons
                        const int32_t *r_len, const int32_t *r_comp, const int32_t *c_slice,
                        const uint32_t *value, int64_t n_runs, void *stream);
 
+/* ---- T1 (yz plane): runs of a yz stack -> dense (Z, Y, X) label volume -----------------------------
+ * replaces the per-pixel decode + sort + re-encode of InstanceTracker.update/finish for axis 'yz'
+ *          empanada/inference/tracker.py:83-88,110-113
+ * The stack has X slices of (Z, Y) pixels; run i covers pixels r_start[i] .. +r_len[i] (flat z*Y+y) of slice
+ * c_slice[r_comp[i]]; voxel (z, y, slice) receives value[r_comp[i]] (0 = skip).  vol must be zeroed.
+ * The 3D run-length encoding along x is then obtained with emp_runs_count / emp_runs_extract on vol.   */
+int emp_scatter_yz_u32(uint32_t *vol, int Z, int Y, int X, const int32_t *r_start, const int32_t *r_len,
+                       const int32_t *r_comp, const int32_t *c_slice, const uint32_t *value,
+                       int64_t n_runs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
