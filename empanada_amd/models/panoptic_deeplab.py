@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-__all__ = ['PanopticDeepLab', 'resnet_encoder', 'prepare_for_inference', 'synthesize_weights']
+__all__ = ['PanopticDeepLab', 'PanopticDeepLabPR', 'PointRendSemSegHead', 'resnet_encoder', 'prepare_for_inference',
+           'synthesize_weights']
 
 _RESNETS = {
     'resnet18': ('basic', [2, 2, 2, 2]), 'resnet34': ('basic', [3, 4, 6, 3]),
@@ -289,6 +290,91 @@ class PanopticDeepLab(nn.Module):
                 'offsets': self._up4(self.ins_xy(ins_x))}
 
 
+# ----------------------------------------------------------------------------- PointRend (inference)
+class StandardPointHead(nn.Module):
+    """Point MLP of 1x1 Conv1d layers; the coarse prediction is re-fed to every layer (point_rend.py:138-190)."""
+
+    def __init__(self, nin, num_classes, fc_dim, num_fc):
+        super().__init__()
+        dim_in = nin + num_classes
+        layers = []
+        for _ in range(num_fc):
+            layers.append(nn.Sequential(nn.Conv1d(dim_in, fc_dim, 1), nn.ReLU(inplace=True)))
+            dim_in = fc_dim + num_classes
+        self.fc_layers = nn.ModuleList(layers)
+        self.predictor = nn.Conv1d(dim_in, num_classes, 1)
+
+    def forward(self, fine, coarse):
+        x = torch.cat([fine, coarse], dim=1)
+        for layer in self.fc_layers:
+            x = torch.cat([layer(x), coarse], dim=1)
+        return self.predictor(x)
+
+
+def _point_sample(features, coords):
+    """bilinear sampling at [0,1]^2 points (N,P,2 as x,y) -> (N,C,P)  (point_rend.py:35-60)"""
+    return F.grid_sample(features, 2.0 * coords.unsqueeze(2) - 1.0, mode='bilinear', align_corners=False).squeeze(3)
+
+
+class PointRendSemSegHead(nn.Module):
+    """Eval-mode PointRend refinement (point_rend.py:241-269): `subdivision_steps` times upsample x2, pick the
+    `subdivision_num_points` most uncertain grid points, re-predict them with the point head from the fine
+    features + coarse logits and scatter them back.  (The training branch is out of scope.)"""
+
+    def __init__(self, nin, num_classes, num_fc=3, train_num_points=1024, oversample_ratio=3,
+                 importance_sample_ratio=0.75, subdivision_steps=2, subdivision_num_points=8192, **kwargs):
+        super().__init__()
+        self.subdivision_steps = subdivision_steps
+        self.subdivision_num_points = subdivision_num_points
+        self.point_head = StandardPointHead(nin, num_classes, nin, num_fc)
+
+    @staticmethod
+    def _uncertainty(logits):
+        if logits.size(1) == 1:
+            return -logits.abs()
+        top2 = torch.topk(logits, k=2, dim=1)[0]
+        return (top2[:, 1] - top2[:, 0]).unsqueeze(1)
+
+    def forward(self, coarse_logits, features):
+        assert not self.training, "only the inference path of PointRend is implemented"
+        logits = coarse_logits.clone()
+        for _ in range(self.subdivision_steps):
+            logits = F.interpolate(logits, scale_factor=2.0, mode='bilinear', align_corners=False)
+            N, C, H, W = logits.shape
+            k = min(H * W, self.subdivision_num_points)
+            idx = torch.topk(self._uncertainty(logits).view(N, H * W), k=k, dim=1)[1]
+            coords = torch.zeros(N, k, 2, dtype=torch.float, device=logits.device)
+            coords[:, :, 0] = 0.5 / W + (idx % W).float() / float(W)
+            coords[:, :, 1] = 0.5 / H + torch.div(idx, W, rounding_mode='floor').float() / float(H)
+            pts = self.point_head(_point_sample(features, coords), _point_sample(coarse_logits, coords))
+            logits = logits.reshape(N, C, H * W).scatter_(2, idx.unsqueeze(1).expand(-1, C, -1), pts).view(N, C, H, W)
+        return {'sem_seg_logits': logits}
+
+
+class PanopticDeepLabPR(PanopticDeepLab):
+    """models/panoptic_deeplab.py:117-160 plus the 3-argument forward of the exported models that the Render
+    engines call (`forward(x, render_steps, interpolate_ins)`, quantization/panoptic_deeplab.py:194-250)."""
+
+    def __init__(self, num_fc=3, train_num_points=1024, oversample_ratio=3, importance_sample_ratio=0.75,
+                 subdivision_steps=2, subdivision_num_points=8192, **kwargs):
+        super().__init__(**kwargs)
+        self.semantic_pr = PointRendSemSegHead(self.decoder_channels, self.num_classes, num_fc, train_num_points,
+                                               oversample_ratio, importance_sample_ratio, subdivision_steps,
+                                               subdivision_num_points)
+
+    def forward(self, x, render_steps: int = 2, interpolate_ins: bool = True):
+        pyramid = self.encoder(x)
+        sem_x = self.semantic_decoder(pyramid)
+        ins_x = sem_x if self.instance_decoder is None else self.instance_decoder(pyramid)
+        self.semantic_pr.subdivision_steps = render_steps
+        # the point head works on NCHW-contiguous fp32 features
+        sem = self.semantic_pr(self.semantic_head(sem_x).float().contiguous(), sem_x.float().contiguous())
+        ctr, off = self.ins_center(ins_x), self.ins_xy(ins_x)
+        return {'sem_logits': sem['sem_seg_logits'],
+                'ctr_hmp': self._up4(ctr) if interpolate_ins else ctr,
+                'offsets': self._up4(off) if interpolate_ins else off}
+
+
 # ----------------------------------------------------------------------------- deployment helpers
 def synthesize_weights(model, scale_bn=True):
     """Deterministic synthetic weights (no trained checkpoints exist offline):
@@ -304,8 +390,8 @@ def synthesize_weights(model, scale_bn=True):
             out[key] = 1 + 0.1 * torch.rand(t.shape, generator=g)
         elif key.endswith('running_mean'):
             out[key] = 0.1 * torch.randn(t.shape, generator=g)
-        elif t.dim() == 4:
-            fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+        elif t.dim() in (3, 4):
+            fan_in = t[0].numel()
             out[key] = torch.randn(t.shape, generator=g) * (2.0 / fan_in) ** 0.5
         elif key.endswith('weight'):
             out[key] = 1 + 0.1 * torch.randn(t.shape, generator=g)

@@ -498,5 +498,39 @@ def main():
     _save('trackers', **cases)
 
 
+    # ------------------------------------------------------------------ D1 model forwards (reference classes)
+    from empanada.models.panoptic_deeplab import PanopticDeepLab as RefPDL
+    from empanada.models.quantization.panoptic_deeplab import QuantizablePanopticDeepLabPR as RefQPR
+    from empanada.models.panoptic_bifpn import PanopticBiFPN as RefBiFPN
+    from empanada.models.quantization.panoptic_bifpn import QuantizablePanopticBiFPNPR as RefQBiFPNPR
+    from empanada_amd.models import PanopticBiFPN, PanopticBiFPNPR, PanopticDeepLab, PanopticDeepLabPR, synthesize_weights
+    cases = {}
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 1, 128, 128, generator=g)
+    cases['x'] = x.numpy()
+    mito = dict(encoder='resnet50', num_classes=1, stage4_stride=16, decoder_channels=256, low_level_stages=[1],
+                low_level_channels_project=[32], atrous_rates=[2, 4, 6], aspp_channels=None, aspp_dropout=0.5,
+                ins_decoder=True, ins_ratio=0.5)
+    for name, ours, ref, args in (
+            ('pdl_r50', PanopticDeepLab(encoder='resnet50', num_classes=1), RefPDL(encoder='resnet50', num_classes=1), ()),
+            ('pdl_r50_c5', PanopticDeepLab(encoder='resnet50', num_classes=5), RefPDL(encoder='resnet50', num_classes=5), ()),
+            ('pdlpr_mito', PanopticDeepLabPR(**mito), RefQPR(quantize=False, **mito), (3, False)),
+            ('bifpn_regnety', PanopticBiFPN(encoder='regnety_6p4gf', num_classes=1),
+             RefBiFPN(encoder='regnety_6p4gf', num_classes=1), ()),
+            ('bifpnpr_r50', PanopticBiFPNPR(encoder='resnet50', num_classes=3, ins_decoder=True),
+             RefQBiFPNPR(quantize=False, encoder='resnet50', num_classes=3, ins_decoder=True), (2, True))):
+        synthesize_weights(ours)            # weights are a function of the state-dict keys only
+        with torch.no_grad():
+            for head in (ours.semantic_head, ours.ins_center, ours.ins_xy):
+                head.head[1].weight.mul_(1e-3)
+        ref.load_state_dict(ours.state_dict(), strict=True)
+        ref.eval()
+        with torch.no_grad():
+            out = ref(x, *args)
+        for k in ('sem_logits', 'ctr_hmp', 'offsets'):
+            cases[f'{name}_{k}'] = out[k].numpy()
+    _save('models', **cases)
+
+
 if __name__ == '__main__':
     main()
