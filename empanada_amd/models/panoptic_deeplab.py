@@ -395,6 +395,11 @@ def synthesize_weights(model, scale_bn=True):
             out[key] = torch.randn(t.shape, generator=g) * (2.0 / fan_in) ** 0.5
         elif key.endswith('weight'):
             out[key] = 1 + 0.1 * torch.randn(t.shape, generator=g)
+            # last BatchNorm of a residual branch: small gamma (as zero-init-residual training leaves it), so that
+            # activations stay O(1) through deep encoders instead of growing block after block
+            if key.endswith(('bn3.weight', 'bottleneck.c.1.weight')) or (key.endswith('bn2.weight') and 'layer' in key
+                                                                          and key.replace('bn2', 'bn3') not in sd):
+                out[key] = 0.25 * out[key]
         else:
             out[key] = 0.05 * torch.randn(t.shape, generator=g)
     model.load_state_dict(out, strict=True)
