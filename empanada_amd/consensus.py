@@ -20,7 +20,8 @@ import torch
 from . import _hip
 from .array_utils import merge_boxes, vote_groups
 
-__all__ = ['merge_objects_from_trackers', 'merge_semantic_from_trackers', 'merge_objects3d', 'object_iou_graph',
+__all__ = ['merge_objects_from_trackers', 'merge_semantic_from_trackers', 'merge_objects_from_tiles',
+           'merge_semantic_from_tiles', 'merge_objects3d', 'object_iou_graph',
            'bounding_box_screening', 'create_graph_of_clusters', 'merge_clusters']
 
 MIN_OVERLAP = 100
@@ -299,6 +300,75 @@ def merge_objects_from_trackers(object_trackers, pixel_vote_thr=2, cluster_iou_t
             instances[iid]['runs'] = rng[:, 1] - rng[:, 0]
             instances[iid] = dict(box=instances[iid]['box'], starts=instances[iid]['starts'],
                                   runs=instances[iid]['runs'])
+    return instances
+
+
+def merge_semantic_from_tiles(tiles):
+    """consensus.py:471-524 -- union of the (single) semantic instance over all tiles."""
+    from .array_utils import join_ranges
+    label_id = None
+    boxes, ranges = [], []
+    for tile_instances in tiles:
+        for instance_id, attr in tile_instances.items():
+            if label_id is None:
+                label_id = instance_id
+            boxes.append(attr['box'])
+            ranges.append(_ranges(attr['starts'], attr['runs']))
+    if len(boxes) == 0:
+        return {}
+    merged_box = np.array(boxes)[0]
+    for box in np.array(boxes)[1:]:
+        merged_box = merge_boxes(merged_box, box)
+    seg_ranges = join_ranges(ranges)
+    return {label_id: {'box': merged_box, 'starts': seg_ranges[:, 0], 'runs': seg_ranges[:, 1] - seg_ranges[:, 0]}}
+
+
+def merge_objects_from_tiles(tiles, overlap_rle=None):
+    """consensus.py:526-625 -- objects of overlapping tiles that intersect are joined; with `overlap_rle`, an object
+    seen in a single tile that lies by more than 10 % inside the overlap region is dropped.  Pair intersections and
+    all joins run on the GPU in one launch each."""
+    from .array_utils import rle_ioa
+    tile_indices, object_labels, object_boxes, object_starts, object_runs = [], [], [], [], []
+    for tile_idx, tile_instances in enumerate(tiles):
+        for instance_id, attr in tile_instances.items():
+            tile_indices.append(tile_idx)
+            object_labels.append(int(instance_id))
+            object_boxes.append(attr['box'])
+            object_starts.append(attr['starts'])
+            object_runs.append(attr['runs'])
+    tile_indices = np.array(tile_indices)
+    object_labels = np.array(object_labels)
+    object_boxes = np.array(object_boxes)
+    if len(object_boxes) == 0:
+        return {}
+    graph = object_iou_graph(tile_indices, object_labels, object_boxes, object_starts, object_runs)
+    if overlap_rle is not None:
+        overlap_starts, overlap_runs = overlap_rle
+
+    clusters = [list(c) for c in nx.connected_components(graph)]
+    groups = []
+    for cluster in clusters:
+        lst = [_ranges(graph.nodes[n]['starts'], graph.nodes[n]['runs']) for n in cluster]
+        if sum(len(r) for r in lst) < 2:
+            raise UnboundLocalError("local variable 'range2' referenced before assignment")   # _join_ranges :659-661
+        groups.append(lst)
+    joined = vote_groups(groups, 1)
+
+    instance_id = int(np.min(object_labels))
+    instances = {}
+    for cluster, voted_ranges in zip(clusters, joined):
+        merged_box = graph.nodes[cluster[0]]['box']
+        for node_id in cluster[1:]:
+            merged_box = merge_boxes(merged_box, graph.nodes[node_id]['box'])
+        if overlap_rle is not None and len(cluster) < 2 and np.any(voted_ranges):
+            ov_ioa = rle_ioa(np.asarray(overlap_starts), np.asarray(overlap_runs), voted_ranges[:, 0],
+                             voted_ranges[:, 1] - voted_ranges[:, 0])
+            if ov_ioa > 0.1:
+                voted_ranges = np.zeros((0, 2), dtype=np.int64)
+        if np.any(voted_ranges):
+            instances[instance_id] = {'box': tuple(int(x) for x in merged_box), 'starts': voted_ranges[:, 0],
+                                      'runs': voted_ranges[:, 1] - voted_ranges[:, 0]}
+            instance_id += 1
     return instances
 
 

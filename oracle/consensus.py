@@ -193,6 +193,61 @@ def merge_objects_from_trackers(object_trackers, pixel_vote_thr=2, cluster_iou_t
     return instances
 
 
+def merge_semantic_from_tiles(tiles):
+    """consensus.py:471-524"""
+    from .rle_ops import join_ranges
+    label_id, boxes, rngs = None, [], []
+    for tile_instances in tiles:
+        for iid, a in tile_instances.items():
+            if label_id is None:
+                label_id = iid
+            boxes.append(a['box'])
+            rngs.append(np.stack([a['starts'], a['starts'] + a['runs']], axis=1))
+    boxes = np.array(boxes)
+    if len(boxes) == 0:
+        return {}
+    box = boxes[0]
+    for b in boxes[1:]:
+        box = merge_boxes(box, b)
+    r = join_ranges(rngs)
+    return {label_id: {'box': box, 'starts': r[:, 0], 'runs': r[:, 1] - r[:, 0]}}
+
+
+def merge_objects_from_tiles(tiles, overlap_rle=None):
+    """consensus.py:526-625"""
+    from .rle_ops import join_ranges, ranges_to_rle, rle_ioa
+    tile_idx, labels, boxes, starts, runs = [], [], [], [], []
+    for ti, tile_instances in enumerate(tiles):
+        for iid, a in tile_instances.items():
+            tile_idx.append(ti)
+            labels.append(int(iid))
+            boxes.append(a['box'])
+            starts.append(a['starts'])
+            runs.append(a['runs'])
+    tile_idx, labels, boxes = np.array(tile_idx), np.array(labels), np.array(boxes)
+    if len(boxes) == 0:
+        return {}
+    graph = object_iou_graph(tile_idx, labels, boxes, starts, runs)
+    instance_id = int(np.min(labels))
+    instances = {}
+    for cluster in nx.connected_components(graph):
+        cluster = list(cluster)
+        box = graph.nodes[cluster[0]]['box']
+        for nid in cluster[1:]:
+            box = merge_boxes(box, graph.nodes[nid]['box'])
+        voted = join_ranges([np.stack([graph.nodes[n]['starts'], graph.nodes[n]['starts'] + graph.nodes[n]['runs']],
+                                      axis=1) for n in cluster])
+        if overlap_rle is not None and len(cluster) < 2 and np.any(voted):
+            rle = ranges_to_rle(voted)
+            if rle_ioa(np.asarray(overlap_rle[0]), np.asarray(overlap_rle[1]), rle[:, 0], rle[:, 1]) > 0.1:
+                voted = []
+        if np.any(voted):
+            instances[instance_id] = {'box': tuple(int(x) for x in box), 'starts': voted[:, 0],
+                                      'runs': voted[:, 1] - voted[:, 0]}
+            instance_id += 1
+    return instances
+
+
 def create_instance_consensus(class_trackers, pixel_vote_thr=2, cluster_iou_thr=0.75, bypass=False):
     """patterns.py:168-186"""
     from .rle_seg import InstanceTracker

@@ -498,6 +498,54 @@ def main():
     _save('trackers', **cases)
 
 
+    # ------------------------------------------------------------------ C5 tiles
+    # cztile is absent; empanada/inference/tile.py imports it at module level.  A stub satisfies the import and a
+    # Tiler is assembled with THIS repository's documented geometry, so that the reference's own
+    # calculate_overlap_rle / translate_rle_seg / merge_objects_from_tiles produce the expected values.
+    cz = types.ModuleType('cztile')
+    cz1 = types.ModuleType('cztile.fixed_total_area_strategy'); cz1.AlmostEqualBorderFixedTotalAreaStrategy2D = object
+    cz2 = types.ModuleType('cztile.tiling_strategy'); cz2.Rectangle = object
+    sys.modules.update({'cztile': cz, 'cztile.fixed_total_area_strategy': cz1, 'cztile.tiling_strategy': cz2})
+    from empanada.inference import tile as TL
+    from empanada_amd.inference.tile import axis_offsets
+    shape = (400, 400)
+    rr = np.arange(-20, 21)
+    circle = ((rr[:, None] ** 2 + rr[None, :] ** 2) <= 400).astype(np.uint32)      # skimage.morphology.disk(20)
+    seg = np.zeros(shape, dtype=np.uint32)
+    c = 1001
+    for xs in range(0, 351, 50):
+        for ys in range(0, 351, 50):
+            seg[ys:ys + 41, xs:xs + 41][circle > 0] = c
+            c += 1
+    seg[380:, 100:300] = 2000                                                        # a semantic (stuff) band
+    cases = {'seg': seg}
+    for ti, (tsize, ov) in enumerate([((100, 110), 20), ((256, 256), 64)]):
+        yr, xr = [], []
+        for y in axis_offsets(shape[0], tsize[0], ov):
+            for x in axis_offsets(shape[1], tsize[1], ov):
+                yr.append((y, y + min(tsize[0], shape[0]))); xr.append((x, x + min(tsize[1], shape[1])))
+        tl = TL.Tiler.__new__(TL.Tiler)
+        tl.image_shape, tl.yranges, tl.xranges = shape, yr, xr
+        ovs, ovr = TL.calculate_overlap_rle(yr, xr, shape)
+        thing_tiles, stuff_tiles = [], []
+        for i in range(len(yr)):
+            crop = seg[yr[i][0]:yr[i][1], xr[i][0]:xr[i][1]]
+            lab = sys.modules['skimage.measure'].label(np.where(crop < 2000, crop, 0)).astype(np.uint32)
+            lab[lab > 0] += 1000
+            lab[crop == 2000] = 2000
+            rs = tl.translate_rle_seg(RL.pan_seg_to_rle_seg(lab, [1, 2], 1000, [1], False), i)
+            thing_tiles.append(rs[1]); stuff_tiles.append(rs[2])
+        cp = lambda tiles: [{k: {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in v.items()} for k, v in t.items()} for t in tiles]
+        merged = CO.merge_objects_from_tiles(cp(thing_tiles))
+        merged_ov = CO.merge_objects_from_tiles(cp(thing_tiles), (ovs, ovr))
+        sem = CO.merge_semantic_from_tiles(cp(stuff_tiles))
+        cases.update({f't{ti}_par': np.array([tsize[0], tsize[1], ov]), f't{ti}_yr': np.array(yr), f't{ti}_xr': np.array(xr),
+                      f't{ti}_ovs': np.asarray(ovs), f't{ti}_ovr': np.asarray(ovr)})
+        cases.update(_pack_instances(merged, f't{ti}_merged'))
+        cases.update(_pack_instances(merged_ov, f't{ti}_mergedov'))
+        cases.update(_pack_instances(sem, f't{ti}_sem'))
+    _save('tiles', n=np.array(2), **cases)
+
     # ------------------------------------------------------------------ D1 model forwards (reference classes)
     from empanada.models.panoptic_deeplab import PanopticDeepLab as RefPDL
     from empanada.models.quantization.panoptic_deeplab import QuantizablePanopticDeepLabPR as RefQPR
