@@ -25,7 +25,7 @@ from .patterns import chain_from_tables, tables_from_stack
 from .postprocess import centers_batched
 
 __all__ = ['shard_bounds', 'merge_rank_tables', 'filter_labels', 'gather_tables_and_chain', 'sharded_panoptic_stack',
-           'sharded_stack_volume']
+           'sharded_tables', 'fill_slab', 'sharded_stack_volume']
 
 
 def _world():
@@ -177,22 +177,34 @@ def sharded_panoptic_stack(sem_prob_local, ctr_hmp_local, offsets_local, *, thin
                               up=step)
 
 
-def sharded_stack_volume(pan_local, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25,
-                         min_size=None, min_span=None, group=None):
-    """Stack mode, steps 3-5: local runs/CC, halo overlaps, global chain on rank 0, local slab fill.
-    Returns the rank's (D_local, H, W) uint32 slab of the labelled volume (device)."""
+def sharded_tables(pan_local, labels, thing_list, label_divisor, group=None):
+    """Stack mode, step 3-4a (device): local runs / connected components and, through a one-slice halo (first
+    label slice of the next rank), the overlaps across the block border.  Returns (RunTable, host tables)."""
     rank, world = _world()
-    D, H, W = pan_local.shape
     pan_ext = pan_local
     if world > 1:
         firsts = _all_gather_cat(pan_local[:1].contiguous().view(torch.int32), group).view(torch.uint32)
         if rank + 1 < world:
             pan_ext = torch.cat([pan_local.view(torch.int32), firsts[rank + 1:rank + 2].view(torch.int32)],
                                 dim=0).view(torch.uint32)
-    table, host = tables_from_stack(pan_ext, labels, thing_list, label_divisor)
-    final = gather_tables_and_chain(host, D, list(labels), list(thing_list), label_divisor, merge_iou_thr,
-                                    merge_ioa_thr, min_size, min_span, group)
-    vol = torch.zeros((D, H, W), dtype=torch.int32, device=pan_local.device).view(torch.uint32)
+    return tables_from_stack(pan_ext, labels, thing_list, label_divisor)
+
+
+def fill_slab(table, final, shape_local):
+    """Stack mode, step 5 (device): paint the rank's (D_local, H, W) uint32 slab from its run table and the final
+    label of every component (0 = dropped)."""
+    D, H, W = shape_local
+    vol = torch.zeros((D, H, W), dtype=torch.int32, device=table.r_start.device).view(torch.uint32)
     if table.n_comp:
         _hip.fill_table_u32(vol, table, _hip.np_to_dev_u32(final), slice0=0)
     return vol
+
+
+def sharded_stack_volume(pan_local, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25,
+                         min_size=None, min_span=None, group=None):
+    """Stack mode, steps 3-5: local runs/CC, halo overlaps, global chain on rank 0, local slab fill.
+    Returns the rank's (D_local, H, W) uint32 slab of the labelled volume (device)."""
+    table, host = sharded_tables(pan_local, labels, thing_list, label_divisor, group)
+    final = gather_tables_and_chain(host, pan_local.shape[0], list(labels), list(thing_list), label_divisor,
+                                    merge_iou_thr, merge_ioa_thr, min_size, min_span, group)
+    return fill_slab(table, final, tuple(pan_local.shape))
