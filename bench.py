@@ -34,14 +34,21 @@ ENGINE = dict(thing_list=[1], label_divisor=20000, stuff_area=64, void_label=0, 
 MATCH = dict(merge_iou_thr=0.25, merge_ioa_thr=0.25)
 FILTERS = dict(min_size=500, min_span=4)
 NORM = dict(mean=0.508979, std=0.148561)                      # MitoNet norms
-# algorithmic HBM bytes per voxel of the hand-written kernels (DESIGN.md "Kernels"), C = 1, full-res heads
+# Algorithmic HBM bytes per voxel of the single-kernel ABI calls, C = 1, full-res heads.
+# f = fraction of voxels whose class is a thing (measured on the run's own data): only those read offsets.
 ALG_BYTES = {
-    'emp_median_harden_stack': 4 + 1,          # read prob fp32, write sem u8
-    'emp_find_centers': 4,                     # read heatmap
-    'emp_group_pixels': 8 + 2,                 # read offsets, write ids u16
-    'emp_fuse_panoptic': 2 * (1 + 2) + 4,      # hist pass + apply pass read sem u8 + ids u16, write pan u32
-    'emp_runs_count': 4,                       # read pan
-    'emp_runs_extract': 4,                     # read pan (+12 B per run)
+    'emp_median_harden_stack': lambda f: 4 + 1,        # read prob fp32, write sem u8
+    'emp_find_centers': lambda f: 4,                   # read heatmap
+    'emp_group_pixels': lambda f: 1 + 8 * f + 2,       # read sem u8, offsets of voted pixels, write ids u16
+    'emp_fuse_apply': lambda f: 1 + 2 + 4,             # read sem u8 + ids u16, write pan u32
+    'emp_runs_count': lambda f: 4,                     # read pan
+    'emp_runs_extract': lambda f: 4,                   # read pan (+12 B per run)
+}
+# HBM traffic per voxel from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, calibrated on known byte counts;
+# profiles/r1_pmc_postproc_256x512x512.md), same workload.  Collected offline: --pmc cannot run inside this script.
+PMC_TRAFFIC_BYTES_PER_VOXEL = {
+    'emp_median_harden_stack': 5.02, 'emp_find_centers': 4.56, 'emp_group_pixels': 4.60, 'emp_fuse_apply': 7.01,
+    'emp_runs_count': 4.02, 'emp_runs_extract': 4.15,
 }
 HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -49,13 +56,13 @@ HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--depth', type=int, default=256, help='slices per rank')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--batch', type=int, default=32, help='slices per model call')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
-    ap.add_argument('--cpu-slices', type=int, default=12, help='slices of the same workload for the CPU baseline')
+    ap.add_argument('--cpu-slices', type=int, default=96, help='slices of the same workload for the CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='run the passes strictly one after the other')
     ap.add_argument('--mode', default='stack', choices=['stack', 'orthoplane'],
@@ -368,10 +375,14 @@ def main():
         post_ms = np.mean([ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(args.steps)])
         kern = {name: float(np.mean([a.elapsed_time(b) for a, b in evs])) for name, evs in prof.items()}
         per_call = {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}
-        # dominant hand-written kernel among the per-voxel ones
+        # dominant hand-written kernel among the per-voxel, single-kernel ABI calls
+        thing_frac = float((heads['sem'] >= ENGINE['confidence_thr']).float().mean().item())
         dom = max((k for k in kern if k in ALG_BYTES), key=lambda k: kern[k])
-        alg = ALG_BYTES[dom] * float(D) * S * S
+        alg_bpv = ALG_BYTES[dom](thing_frac)
+        alg = alg_bpv * float(D) * S * S
         ach = alg / (kern[dom] * 1e-3) / 1e9
+        roofs = {k: round(ALG_BYTES[k](thing_frac) * float(D) * S * S / (kern[k] * 1e-3) / 1e9, 1)
+                 for k in kern if k in ALG_BYTES}
         flops = 414477.0 * D * S * S                                      # PDL-R50, C=1
         res = {
             'metric': 'Mvox/s end-to-end 3D panoptic inference (incl. consensus); PQ vs CPU ref',
@@ -389,8 +400,11 @@ def main():
                              'host_chain_s': round(float(np.mean(pipe.timers.get('chain_s', [0]))), 4)},
             'hip_calls_ms': per_call,
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
-                         'alg_bytes_per_voxel': ALG_BYTES[dom]},
+                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                         'traffic': round(PMC_TRAFFIC_BYTES_PER_VOXEL[dom] * float(D) * S * S),
+                         'alg_bytes_per_launch': round(alg), 'alg_bytes_per_voxel': round(alg_bpv, 3),
+                         'avg_launch_ms': round(kern[dom], 4), 'thing_fraction': round(thing_frac, 4),
+                         'all_kernels_GBps': roofs},
         }
         if not args.no_cpu_baseline and world == 1:
             log('cpu baseline')

@@ -41,6 +41,8 @@ SIGNATURES = {
     'emp_group_pixels': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _U32, _P, _P]),
     'emp_fuse_work_elems': (_L, [_I, _I, _I]),
     'emp_fuse_panoptic': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _U32, _L, _L, _L, _P, _P, _P, _P]),
+    'emp_fuse_lut': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _U32, _L, _L, _P, _P]),
+    'emp_fuse_apply': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _U32, _L, _L, _P, _P, _P, _P]),
     'emp_runs_count': (_I, [_P, _I, _I, _I, _P, _P]),
     'emp_scan_tmp_elems': (_L, [_L]),
     'emp_exclusive_scan_i32': (_I, [_P, _L, _P, _P, _P]),
@@ -201,8 +203,11 @@ def fuse_panoptic(sem, ids, cap, n_classes, thing_list, label_divisor, stuff_are
     p32 = _ptr(pan) if out_dtype == torch.uint32 else None
     p64 = _ptr(pan) if out_dtype == torch.int64 else None
     assert (p32 is None) != (p64 is None), "out_dtype must be torch.uint32 or torch.int64"
-    call('emp_fuse_panoptic', _ptr(sem.contiguous()), _ptr(ids.contiguous()), D, H, W, int(up), int(cap),
-         int(n_classes), mask, int(label_divisor), int(stuff_area), int(void_label), _ptr(work), p32, p64, stream())
+    sem, ids = sem.contiguous(), ids.contiguous()
+    call('emp_fuse_lut', _ptr(sem), _ptr(ids), D, H, W, int(up), int(cap), int(n_classes), mask, int(label_divisor),
+         int(stuff_area), _ptr(work), stream())
+    call('emp_fuse_apply', _ptr(sem), _ptr(ids), D, H, W, int(up), int(cap), int(n_classes), mask, int(label_divisor),
+         int(void_label), _ptr(work), p32, p64, stream())
     return pan
 
 

@@ -274,38 +274,53 @@ __global__ __launch_bounds__(256) void find_centers_kernel(const float *__restri
     const int64_t hw = (int64_t)h * w;
     const int lane = threadIdx.x & 63;
     const bool need_left = (k / 2) >= 1, need_right = (k - 1 - k / 2) >= 1;
-    // wave-uniform loop bounds: all 64 lanes take part in the shuffles of every iteration
+    // wave-uniform loop bounds: all 64 lanes take part in the shuffles of every iteration.  Each lane issues
+    // FC_U independent 16-byte loads before touching any of them (4 KiB in flight per wave).
+    constexpr int FC_U = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * VEC;
     const int64_t wave_q0 = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * VEC;
-    for (int64_t base = wave_q0; base < hw; base += (int64_t)gridDim.x * blockDim.x * VEC) {
-        const int64_t q = base + (int64_t)lane * VEC;
-        bool live = q < hw;
-        float v[VEC + 2];
-        if (VEC == 4) {
-            float4 f = live ? *reinterpret_cast<const float4 *>(img + q) : make_float4(-1.f, -1.f, -1.f, -1.f);
-            v[1] = f.x; v[2] = f.y; v[3] = f.z; v[4] = f.w;
-        } else {
-            v[1] = live ? img[q] : -1.f;
-        }
-        const int y = live ? (int)(q / w) : 0, x = live ? (int)(q % w) : 0;
-        float left = __shfl_up(v[VEC], 1), right = __shfl_down(v[1], 1);
-        // neighbours across the wave edge or the row edge come from memory (or do not exist)
-        if (lane == 0 || x == 0) left = (live && x > 0) ? img[q - 1] : -INFINITY;
-        if (lane == 63 || x + VEC >= w) right = (live && x + VEC < w) ? img[q + VEC] : -INFINITY;
-        v[0] = left;
-        v[VEC + 1] = right;
-        if (!live) continue;
+    for (int64_t base0 = wave_q0; base0 < hw; base0 += stride * FC_U) {
+        float vv[FC_U][VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            float c = v[j + 1];
-            if (!(c > thr && c > 0.0f)) continue;
-            if (need_left && x + j > 0 && thresholded(v[j], thr) > c) continue;
-            if (need_right && x + j + 1 < w && thresholded(v[j + 2], thr) > c) continue;
-            // same necessary condition along the column (prunes the ridge of every blob down to its peak)
-            if (need_left && y > 0 && thresholded(img[q + j - w], thr) > c) continue;
-            if (need_right && y + 1 < h && thresholded(img[q + j + w], thr) > c) continue;
-            if (is_window_max(img, h, w, y, x + j, c, thr, k)) {
-                int slot = atomicAdd(&out_count[d], 1);
-                if (slot < cap) out_idx[(int64_t)d * cap + slot] = y * w + x + j;
+        for (int u = 0; u < FC_U; ++u) {
+            const int64_t q = base0 + u * stride + (int64_t)lane * VEC;
+            if (VEC == 4) {
+                float4 f = (q < hw) ? *reinterpret_cast<const float4 *>(img + q) : make_float4(-1.f, -1.f, -1.f, -1.f);
+                vv[u][0] = f.x; vv[u][1] = f.y; vv[u][2] = f.z; vv[u][3] = f.w;
+            } else {
+                vv[u][0] = (q < hw) ? img[q] : -1.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FC_U; ++u) {
+            const int64_t base = base0 + u * stride;
+            if (base >= hw) break;                                   // wave-uniform
+            const int64_t q = base + (int64_t)lane * VEC;
+            const bool live = q < hw;
+            float v[VEC + 2];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j + 1] = vv[u][j];
+            const int y = live ? (int)(q / w) : 0, x = live ? (int)(q % w) : 0;
+            float left = __shfl_up(v[VEC], 1), right = __shfl_down(v[1], 1);
+            // neighbours across the wave edge or the row edge come from memory (or do not exist)
+            if (lane == 0 || x == 0) left = (live && x > 0) ? img[q - 1] : -INFINITY;
+            if (lane == 63 || x + VEC >= w) right = (live && x + VEC < w) ? img[q + VEC] : -INFINITY;
+            v[0] = left;
+            v[VEC + 1] = right;
+            if (!live) continue;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float c = v[j + 1];
+                if (!(c > thr && c > 0.0f)) continue;
+                if (need_left && x + j > 0 && thresholded(v[j], thr) > c) continue;
+                if (need_right && x + j + 1 < w && thresholded(v[j + 2], thr) > c) continue;
+                // same necessary condition along the column (prunes the ridge of every blob down to its peak)
+                if (need_left && y > 0 && thresholded(img[q + j - w], thr) > c) continue;
+                if (need_right && y + 1 < h && thresholded(img[q + j + w], thr) > c) continue;
+                if (is_window_max(img, h, w, y, x + j, c, thr, k)) {
+                    int slot = atomicAdd(&out_count[d], 1);
+                    if (slot < cap) out_idx[(int64_t)d * cap + slot] = y * w + x + j;
+                }
             }
         }
     }
@@ -355,11 +370,11 @@ extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr
     const bool vec4 = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(hmp) & 15) == 0);
     const int64_t hw = (int64_t)h * w;
     if (vec4) {
-        int gx = emp_grid(hw / 4, 256, 512);
+        int gx = emp_grid(emp_cdiv(hw / 4, 4), 256, 512);
         hipLaunchKernelGGL(find_centers_kernel<4>, dim3(gx, D), dim3(256), 0, st, hmp, h, w, thr, k, cap, out_idx,
                            out_count);
     } else {
-        int gx = emp_grid(hw, 256, 1024);
+        int gx = emp_grid(emp_cdiv(hw, 4), 256, 1024);
         hipLaunchKernelGGL(find_centers_kernel<1>, dim3(gx, D), dim3(256), 0, st, hmp, h, w, thr, k, cap, out_idx,
                            out_count);
     }
@@ -378,10 +393,11 @@ extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr
 // semantic map, only thing pixels with one -- ~10 % of an EM slice) are compacted into an LDS list so that the
 // K-centre loop runs with full lanes; ids are staged in LDS and written back as one coalesced 16-byte store
 // per lane.  Traffic: 1 B (class) + 8 B (offsets, voted pixels only) read, 2 B written per pixel.
-#define GP_TILE 2048
-#define GP_PER_THREAD (GP_TILE / 256)
+#define GP_THREADS 128
+#define GP_TILE 1024
+#define GP_PER_THREAD (GP_TILE / GP_THREADS)
 
-__global__ __launch_bounds__(256) void group_pixels_kernel(const int32_t *__restrict__ ctr_idx,
+__global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const int32_t *__restrict__ ctr_idx,
                                                            const int32_t *__restrict__ ctr_count, int cap,
                                                            const float *__restrict__ offsets, int h, int w,
                                                            int step, const uint8_t *__restrict__ sem,
@@ -490,7 +506,7 @@ extern "C" int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count
     if (D == 0) return EMP_OK;
     int64_t hw = (int64_t)h * w;
     int gx = (int)emp_cdiv(hw, GP_TILE);
-    hipLaunchKernelGGL(group_pixels_kernel, dim3(gx, D), dim3(256), (size_t)cap * sizeof(float2), emp_stream(stream),
+    hipLaunchKernelGGL(group_pixels_kernel, dim3(gx, D), dim3(GP_THREADS), (size_t)cap * sizeof(float2), emp_stream(stream),
                        ctr_idx, ctr_count, cap, offsets, h, w, step, sem, thing_mask, out_ids);
     EMP_CHECK_LAUNCH("emp_group_pixels");
     return EMP_OK;
@@ -794,18 +810,31 @@ __global__ __launch_bounds__(256) void fuse_hist_vec4_kernel(const uint8_t *__re
     }
 }
 
-extern "C" int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D, int H, int W, int up, int cap,
-                                 int n_classes, uint32_t thing_mask, int64_t label_divisor, int64_t stuff_area,
-                                 int64_t void_label, int32_t *work, uint32_t *out_pan_u32,
-                                 int64_t *out_pan_i64, void *stream)
+static bool fuse_vec4_ok(const uint8_t *sem, const uint16_t *ids, const void *out, int W, int up)
+{
+    // 4-pixel-per-lane kernels need aligned rows and ids that are either per pixel or shared by the 4 pixels
+    return (W % 4 == 0) && (up == 1 || up % 4 == 0) && ((reinterpret_cast<uintptr_t>(sem) & 3) == 0) &&
+           ((reinterpret_cast<uintptr_t>(ids) & 7) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+}
+
+static int fuse_check(const uint8_t *sem, const uint16_t *ids, int D, int H, int W, int up, int cap, int n_classes,
+                      int64_t label_divisor, const int32_t *work)
 {
     EMP_REQUIRE(sem && ids && work, "fuse: null pointer");
-    EMP_REQUIRE((out_pan_u32 != nullptr) != (out_pan_i64 != nullptr), "fuse: exactly one output must be given");
     EMP_REQUIRE(up >= 1 && H % up == 0 && W % up == 0, "fuse: H,W must be multiples of up=%d", up);
     EMP_REQUIRE(n_classes >= 1 && n_classes <= EMP_MAX_CLASSES, "fuse: n_classes out of range");
     EMP_REQUIRE(cap >= 1 && cap <= 65535, "fuse: cap out of range");
     EMP_REQUIRE(D >= 0 && D <= 65535 && H > 0 && W > 0, "fuse: bad shape");
     EMP_REQUIRE(label_divisor > 0 && (n_classes * label_divisor) < (1LL << 32), "fuse: labels exceed 32 bits");
+    return EMP_OK;
+}
+
+extern "C" int emp_fuse_lut(const uint8_t *sem, const uint16_t *ids, int D, int H, int W, int up, int cap,
+                            int n_classes, uint32_t thing_mask, int64_t label_divisor, int64_t stuff_area,
+                            int32_t *work, void *stream)
+{
+    int rc = fuse_check(sem, ids, D, H, W, up, cap, n_classes, label_divisor, work);
+    if (rc != EMP_OK) return rc;
     if (D == 0) return EMP_OK;
     hipStream_t st = emp_stream(stream);
     FuseLayout L = fuse_layout(D, cap, n_classes);
@@ -813,28 +842,39 @@ extern "C" int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D,
         EMP_FAIL(EMP_ELAUNCH, "fuse: memset failed");
     int64_t HW = (int64_t)H * W;
     int gx = emp_grid(HW, 256, 1024);
-    // 4-pixel-per-lane kernels need aligned rows and ids that are either per pixel or shared by the 4 pixels
-    const bool vec4 = (W % 4 == 0) && (up == 1 || up % 4 == 0) &&
-                      ((reinterpret_cast<uintptr_t>(sem) & 3) == 0) && ((reinterpret_cast<uintptr_t>(ids) & 7) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(out_pan_u32 ? (void *)out_pan_u32 : (void *)out_pan_i64) & 15) == 0);
-    {
-        // ~8K pixels per block keeps the flush cheap; D * gh blocks fill the chip
-        int gh = (int)emp_cdiv(HW, 8192);
-        if ((int64_t)gh * D < 1024) gh = (int)emp_cdiv(1024, D);
-        if (gh > gx) gh = gx;
-        size_t lds = ((size_t)(cap + 1) * n_classes + n_classes) * sizeof(int32_t);
-        int use_lds = lds <= 48 * 1024;
-        if (vec4 && use_lds)
-            hipLaunchKernelGGL(fuse_hist_vec4_kernel, dim3(gh, D), dim3(256), lds, st, sem, ids, H, W, up, cap,
-                               n_classes, thing_mask, work + L.hist, work + L.stuff);
-        else
-            hipLaunchKernelGGL(fuse_hist_kernel, dim3(gh, D), dim3(256), use_lds ? lds : 0, st, sem, ids, H, W, up,
-                               cap, n_classes, thing_mask, work + L.hist, work + L.stuff, use_lds);
-    }
-    EMP_CHECK_LAUNCH("emp_fuse_panoptic(hist)");
+    const bool vec4 = fuse_vec4_ok(sem, ids, nullptr, W, up);
+    // ~8K pixels per block keeps the flush cheap; D * gh blocks fill the chip
+    int gh = (int)emp_cdiv(HW, 8192);
+    if ((int64_t)gh * D < 1024) gh = (int)emp_cdiv(1024, D);
+    if (gh > gx) gh = gx;
+    size_t lds = ((size_t)(cap + 1) * n_classes + n_classes) * sizeof(int32_t);
+    int use_lds = lds <= 48 * 1024;
+    if (vec4 && use_lds)
+        hipLaunchKernelGGL(fuse_hist_vec4_kernel, dim3(gh, D), dim3(256), lds, st, sem, ids, H, W, up, cap, n_classes,
+                           thing_mask, work + L.hist, work + L.stuff);
+    else
+        hipLaunchKernelGGL(fuse_hist_kernel, dim3(gh, D), dim3(256), use_lds ? lds : 0, st, sem, ids, H, W, up, cap,
+                           n_classes, thing_mask, work + L.hist, work + L.stuff, use_lds);
+    EMP_CHECK_LAUNCH("emp_fuse_lut(hist)");
     hipLaunchKernelGGL(fuse_lut_kernel, dim3(D), dim3(256), 0, st, cap, n_classes, thing_mask, label_divisor,
                        stuff_area, work + L.hist, work + L.stuff, work + L.lut, work + L.ok);
-    EMP_CHECK_LAUNCH("emp_fuse_panoptic(lut)");
+    EMP_CHECK_LAUNCH("emp_fuse_lut(lut)");
+    return EMP_OK;
+}
+
+extern "C" int emp_fuse_apply(const uint8_t *sem, const uint16_t *ids, int D, int H, int W, int up, int cap,
+                              int n_classes, uint32_t thing_mask, int64_t label_divisor, int64_t void_label,
+                              const int32_t *work, uint32_t *out_pan_u32, int64_t *out_pan_i64, void *stream)
+{
+    int rc = fuse_check(sem, ids, D, H, W, up, cap, n_classes, label_divisor, work);
+    if (rc != EMP_OK) return rc;
+    EMP_REQUIRE((out_pan_u32 != nullptr) != (out_pan_i64 != nullptr), "fuse: exactly one output must be given");
+    if (D == 0) return EMP_OK;
+    hipStream_t st = emp_stream(stream);
+    FuseLayout L = fuse_layout(D, cap, n_classes);
+    int64_t HW = (int64_t)H * W;
+    int gx = emp_grid(HW, 256, 1024);
+    const bool vec4 = fuse_vec4_ok(sem, ids, out_pan_u32 ? (void *)out_pan_u32 : (void *)out_pan_i64, W, up);
     if (vec4) {
         int gv = emp_grid(HW / 4, 256, 1024);
         if (out_pan_u32)
@@ -853,8 +893,20 @@ extern "C" int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D,
         hipLaunchKernelGGL(fuse_apply_kernel<int64_t>, dim3(gx, D), dim3(256), 0, st, sem, ids, H, W, up, cap,
                            n_classes, thing_mask, label_divisor, void_label, work + L.lut, work + L.ok,
                            out_pan_i64);
-    EMP_CHECK_LAUNCH("emp_fuse_panoptic(apply)");
+    EMP_CHECK_LAUNCH("emp_fuse_apply");
     return EMP_OK;
+}
+
+extern "C" int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D, int H, int W, int up, int cap,
+                                 int n_classes, uint32_t thing_mask, int64_t label_divisor, int64_t stuff_area,
+                                 int64_t void_label, int32_t *work, uint32_t *out_pan_u32,
+                                 int64_t *out_pan_i64, void *stream)
+{
+    EMP_REQUIRE((out_pan_u32 != nullptr) != (out_pan_i64 != nullptr), "fuse: exactly one output must be given");
+    int rc = emp_fuse_lut(sem, ids, D, H, W, up, cap, n_classes, thing_mask, label_divisor, stuff_area, work, stream);
+    if (rc != EMP_OK) return rc;
+    return emp_fuse_apply(sem, ids, D, H, W, up, cap, n_classes, thing_mask, label_divisor, void_label, work,
+                          out_pan_u32, out_pan_i64, stream);
 }
 
 // ------------------------------------------------------------------------------------------

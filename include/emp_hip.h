@@ -115,6 +115,14 @@ int emp_fuse_panoptic(const uint8_t *sem, const uint16_t *ids, int D, int H, int
                       int cap, int n_classes, uint32_t thing_mask, int64_t label_divisor,
                       int64_t stuff_area, int64_t void_label, int32_t *work,
                       uint32_t *out_pan_u32, int64_t *out_pan_i64, void *stream);
+/* The two halves of emp_fuse_panoptic, for callers that keep the per-slice tables (and so that each pass can be
+ * timed on its own): emp_fuse_lut = histogram + per-slice label table into `work`; emp_fuse_apply = label pass.   */
+int emp_fuse_lut(const uint8_t *sem, const uint16_t *ids, int D, int H, int W, int up, int cap,
+                 int n_classes, uint32_t thing_mask, int64_t label_divisor, int64_t stuff_area,
+                 int32_t *work, void *stream);
+int emp_fuse_apply(const uint8_t *sem, const uint16_t *ids, int D, int H, int W, int up, int cap,
+                   int n_classes, uint32_t thing_mask, int64_t label_divisor, int64_t void_label,
+                   const int32_t *work, uint32_t *out_pan_u32, int64_t *out_pan_i64, void *stream);
 
 /* ---- R1-R3: run extraction + 8-connected components on runs --------------------------------
  * replaces connected_components                    empanada/inference/rle.py:18-24
