@@ -13,7 +13,7 @@ import numpy as np
 
 from .array_utils import numpy_fill_instances, put, rle_to_ranges, take
 
-__all__ = ['zarr_fill_instances', 'chunk_ranges', 'zarr_put3d', 'zarr_take3d', 'ChunkedArray']
+__all__ = ['zarr_fill_instances', 'chunk_ranges', 'zarr_put3d', 'zarr_take3d', 'ChunkedArray', 'ZarrData']
 
 
 class ChunkedArray:
@@ -110,3 +110,21 @@ def zarr_put3d(stack, index, value, axis):
 def zarr_take3d(stack, index, axis):
     """scripts/inference3d_multigpu.py:512 -- read one slice along `axis` (array_utils.take :6-23)."""
     return take(stack, index, axis)
+
+
+class ZarrData:
+    """`ZarrData(volume, axis, tfs)` (scripts/inference3d_multigpu.py:318) does not exist in the reference: a
+    map-style dataset over the slices of `volume` along `axis` yielding {'index', 'image'} like
+    empanada/data/volume_dataset.py:7-53 (`tfs(image=...)['image']` is applied when given)."""
+
+    def __init__(self, volume, axis=0, tfs=None):
+        self.volume, self.axis, self.tfs = volume, axis, tfs
+
+    def __len__(self):
+        return self.volume.shape[self.axis]
+
+    def __getitem__(self, idx):
+        image = np.asarray(take(self.volume, idx, self.axis))
+        if self.tfs is not None:
+            image = self.tfs(image=image)['image']
+        return {'index': idx, 'image': image}

@@ -1,0 +1,126 @@
+"""GPU: edge cases of the whole-stack path against the oracle chain -- empty stacks, no centres, everything
+foreground, odd sizes (scalar kernel paths), single slice, ks = 1, centre-capacity growth, multi-class with stuff."""
+import numpy as np
+import pytest
+import torch
+
+from empanada_amd import synthetic as SY
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(thing_list=[1], label_divisor=1000, stuff_area=16, void_label=0, nms_threshold=0.1, nms_kernel=7,
+          confidence_thr=0.5, median_kernel_size=3)
+
+
+def oracle_volume(sem, ctr, off, kw, labels, shape, coarse=False, min_size=None, min_span=None):
+    from oracle import postprocess as OP
+    from oracle import rle_ops as OR
+    from oracle import rle_seg as OS
+    S = len(sem)
+    pans = OP.engine3d_stack([sem[t:t + 1] for t in range(S)], [ctr[t:t + 1] for t in range(S)],
+                             [off[t:t + 1] for t in range(S)], coarse_boundaries=coarse, render=True, **kw)
+    pans = [p.squeeze(0) if p.ndim == 3 else p for p in pans]
+    pans = [p.reshape(shape[1:]) for p in pans]
+    matchers = OS.create_matchers(kw['thing_list'], kw['label_divisor'], 0.25, 0.25)
+    stack = OS.forward_matching(pans, matchers, labels, kw['label_divisor'], kw['thing_list'])
+    trs = OS.create_axis_trackers(['xy'], labels, kw['label_divisor'], (len(pans),) + shape[1:])['xy']
+    for idx, rs in OS.backward_matching(stack, matchers, len(pans)):
+        OS.update_trackers(rs, idx, trs)
+    OS.finish_tracking(trs)
+    vol = np.zeros((len(pans),) + shape[1:], np.uint32)
+    for tr in trs:
+        if min_size is not None:
+            OS.remove_small_objects(tr, min_size)
+        if min_span is not None:
+            OS.remove_pancakes(tr, min_span)
+        OR.numpy_fill_instances(vol, tr.instances)
+    return np.stack(pans), vol
+
+
+def product_volume(sem, ctr, off, kw, labels, coarse=False, min_size=None, min_span=None):
+    from empanada_amd.inference import sharded
+    from empanada_amd.inference.postprocess import panoptic_stack
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    pan, emitted = panoptic_stack(t(sem), t(ctr), t(off), coarse_boundaries=coarse, **kw)
+    vol = sharded.sharded_stack_volume(pan, labels, kw['thing_list'], kw['label_divisor'], 0.25, 0.25,
+                                       min_size=min_size, min_span=min_span)
+    return pan.cpu().numpy().astype(np.int64), vol.cpu().numpy()
+
+
+def check(sem, ctr, off, kw=KW, labels=(1,), coarse=False, **flt):
+    shape = (sem.shape[0],) + sem.shape[-2:]
+    epan, evol = oracle_volume(sem, ctr, off, kw, list(labels), shape, coarse, **flt)
+    gpan, gvol = product_volume(sem, ctr, off, kw, list(labels), coarse, **flt)
+    np.testing.assert_array_equal(gpan, epan)
+    np.testing.assert_array_equal(gvol, evol)
+    return gvol
+
+
+def test_all_background_and_no_centres():
+    sem = np.full((5, 1, 32, 48), 0.1, np.float32)
+    ctr = np.zeros((5, 1, 32, 48), np.float32)
+    off = np.zeros((5, 2, 32, 48), np.float32)
+    assert check(sem, ctr, off).max() == 0
+    sem[:] = 0.9            # foreground everywhere but no centre: thing pixels with instance 0 stay void
+    assert check(sem, ctr, off).max() == 0
+
+
+def test_everything_foreground_single_centre():
+    sem = np.full((4, 1, 40, 40), 0.9, np.float32)
+    ctr = np.zeros((4, 1, 40, 40), np.float32)
+    ctr[:, 0, 20, 20] = 1.0
+    off = np.zeros((4, 2, 40, 40), np.float32)
+    vol = check(sem, ctr, off)
+    assert (vol == 1001).all()
+
+
+@pytest.mark.parametrize('shape', [(6, 37, 53), (1, 64, 64), (3, 33, 130)])
+@pytest.mark.parametrize('ks', [1, 3])
+def test_odd_sizes_and_short_stacks(shape, ks):
+    D, H, W = shape
+    lab, cls = SY.planted_labels(shape, fill=0.25, rmin=3, rmax=9, seed=D * 7 + H)
+    h = SY.planted_heads(lab, cls, 'xy', seed=H)
+    kw = dict(KW, median_kernel_size=ks)
+    check(h['sem'].numpy(), h['ctr_hmp'].numpy(), h['offsets'].numpy(), kw, min_size=20, min_span=2)
+
+
+def test_centre_capacity_grows():
+    """more than 256 centres in a slice: the first capacity overflows and the host retries with a larger one"""
+    rng = np.random.default_rng(0)
+    H = W = 256
+    ctr = np.zeros((2, 1, H, W), np.float32)
+    ys, xs = np.meshgrid(np.arange(4, H, 12), np.arange(4, W, 12), indexing='ij')
+    ctr[:, 0, ys.ravel(), xs.ravel()] = (0.5 + 0.5 * rng.random(ys.size)).astype(np.float32)
+    assert ys.size > 256
+    sem = (rng.random((2, 1, H, W)) > 0.3).astype(np.float32)
+    off = rng.normal(0, 2, (2, 2, H, W)).astype(np.float32)
+    vol = check(sem, ctr, off)
+    assert len(np.unique(vol)) > 100
+
+
+def test_too_many_centres_raises():
+    from empanada_amd import _hip
+    from empanada_amd.inference.postprocess import centers_batched
+    hm = torch.zeros((1, 1, 300, 300), device='cuda')
+    hm[0, 0, ::2, ::2] = torch.rand(150, 150, device='cuda') * 0.5 + 0.5       # 22500 isolated maxima at k = 1
+    with pytest.raises(_hip.HipError):
+        centers_batched(hm, 0.1, 1)
+
+
+def test_multiclass_with_stuff_and_coarse_heads():
+    shape = (7, 64, 64)
+    lab, cls = SY.planted_labels(shape, fill=0.3, rmin=4, rmax=10, seed=21, n_classes=3)
+    h = SY.planted_heads(lab, cls, 'xy', n_classes=3, seed=5, coarse=True)
+    kw = dict(KW, thing_list=[1, 2], stuff_area=40)
+    vol = check(h['sem'].numpy(), h['ctr_hmp'].numpy(), h['offsets'].numpy(), kw, labels=(1, 2, 3), coarse=True)
+    assert (vol == 3000).any() and (vol // 1000 == 1).any() and (vol // 1000 == 2).any()
+
+
+def test_argument_errors_are_loud():
+    from empanada_amd import _hip
+    from empanada_amd.inference.postprocess import group_pixels, panoptic_stack
+    with pytest.raises(ValueError):
+        group_pixels(torch.zeros(1, 2, dtype=torch.long), torch.zeros(2, 2, 8, 8))
+    with pytest.raises(_hip.HipError):     # heads at a resolution the step does not explain
+        panoptic_stack(torch.rand(2, 1, 30, 30).cuda(), torch.rand(2, 1, 30, 30).cuda(), torch.rand(2, 2, 30, 30).cuda(),
+                       coarse_boundaries=True, **KW)
