@@ -38,7 +38,8 @@ SIGNATURES = {
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
     'emp_find_centers': (_I, [_P, _I, _I, _I, _F, _I, _I, _P, _P, _P]),
-    'emp_group_pixels': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _U32, _P, _P]),
+    'emp_group_work_elems': (_L, [_I, _I]),
+    'emp_group_pixels': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _U32, _P, _P, _P]),
     'emp_fuse_work_elems': (_L, [_I, _I, _I]),
     'emp_fuse_panoptic': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _U32, _L, _L, _L, _P, _P, _P, _P]),
     'emp_fuse_lut': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _U32, _L, _L, _P, _P]),
@@ -184,8 +185,9 @@ def group_pixels(idx, cnt, offsets, step, sem=None, thing_list=()):
         mask |= 1 << int(t)
     if sem is not None:
         assert sem.shape == (D, h, w) and sem.dtype == torch.uint8
+    work = torch.empty((query('emp_group_work_elems', D, idx.shape[1]),), dtype=torch.float32, device=offsets.device)
     call('emp_group_pixels', _ptr(idx), _ptr(cnt), idx.shape[1], _ptr(offsets), D, h, w, int(step),
-         _ptr(sem.contiguous()) if sem is not None else None, mask, _ptr(ids), stream())
+         _ptr(sem.contiguous()) if sem is not None else None, mask, _ptr(work), _ptr(ids), stream())
     return ids
 
 

@@ -393,17 +393,41 @@ extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr
 // semantic map, only thing pixels with one -- ~10 % of an EM slice) are compacted into an LDS list so that the
 // K-centre loop runs with full lanes; ids are staged in LDS and written back as one coalesced 16-byte store
 // per lane.  Traffic: 1 B (class) + 8 B (offsets, voted pixels only) read, 2 B written per pixel.
+#define GP_BATCH 8
 #define GP_THREADS 128
 #define GP_TILE 1024
 #define GP_PER_THREAD (GP_TILE / GP_THREADS)
 
-__global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const int32_t *__restrict__ ctr_idx,
+// correctly rounded fp32 square root: the double-precision root of a float rounds to the correctly rounded float
+// root (53 >= 2*24 + 2), independent of how v_sqrt_f32 is refined by the compiler flags in use
+__device__ __forceinline__ float sqrt_rn_exact(float s) { return (float)__dsqrt_rn((double)s); }
+
+// centres of every slice as fp32 (step*y, step*x): step * ctr is int64 * python float -> fp32 (postprocess.py:151)
+__global__ void group_centers_kernel(const int32_t *__restrict__ ctr_idx, const int32_t *__restrict__ ctr_count,
+                                     int cap, int w, int step, int D, float2 *__restrict__ ctr_f)
+{
+    const float fstep = (float)step;
+    // slice d owns ctr_f[d*stride .. d*stride + cap + 2*GP_BATCH); entries past its K are +inf (never the nearest)
+    const int stride = cap + 2 * GP_BATCH;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)D * stride;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int d = (int)(i / stride), k = (int)(i % stride);
+        int n = ctr_count[d] < cap ? ctr_count[d] : cap;
+        float2 v = make_float2(INFINITY, INFINITY);
+        if (k < n) {
+            int f = ctr_idx[(int64_t)d * cap + k];
+            v = make_float2(__fmul_rn(fstep, (float)(f / w)), __fmul_rn(fstep, (float)(f % w)));
+        }
+        ctr_f[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *__restrict__ ctr_f,
                                                            const int32_t *__restrict__ ctr_count, int cap,
                                                            const float *__restrict__ offsets, int h, int w,
                                                            int step, const uint8_t *__restrict__ sem,
                                                            uint32_t thing_mask, uint16_t *__restrict__ out_ids)
 {
-    extern __shared__ float2 ctr[];  // cap entries
     __shared__ uint16_t todo[GP_TILE];
     __shared__ __attribute__((aligned(16))) uint16_t ids_tile[GP_TILE];
     __shared__ int n_todo;
@@ -411,20 +435,16 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const int32_t 
     int K = ctr_count[d];
     if (K > cap) K = cap;
     const int64_t hw = (int64_t)h * w;
-    const float fstep = (float)step;
     if (threadIdx.x == 0) n_todo = 0;
-    for (int i = threadIdx.x; i < K; i += blockDim.x) {
-        int f = ctr_idx[(int64_t)d * cap + i];
-        // step * ctr: int64 * python float -> fp32 tensor (postprocess.py:151)
-        ctr[i] = make_float2(__fmul_rn(fstep, (float)(f / w)), __fmul_rn(fstep, (float)(f % w)));
-    }
     __syncthreads();
+    // the slice's centres are read with a wave-uniform index: scalar loads, operands straight from SGPRs
+    const float2 *__restrict__ ctr = ctr_f + (int64_t)d * (cap + 2 * GP_BATCH);
     const float *offy = offsets + (int64_t)d * 2 * hw;
     const float *offx = offy + hw;
     uint16_t *out = out_ids + (int64_t)d * hw;
     const uint8_t *sm = sem ? sem + (int64_t)d * hw : nullptr;
     const int64_t tile0 = (int64_t)blockIdx.x * GP_TILE;
-    const float dinit = (K > 20) ? 1e5f : INFINITY;
+    const float sinit = (K > 20) ? 1e10f : INFINITY;   // sqrt_rn(1e10f) == 1e5f exactly
     const int idinit = (K > 20 || K == 0) ? 0 : 1;
 
     // phase 1: which pixels of the tile are voted on
@@ -449,8 +469,20 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const int32_t 
     if (K == 0) wantbits = 0;
 #pragma unroll
     for (int j = 0; j < GP_PER_THREAD; ++j) ids_tile[l0 + j] = 0;
+    // compaction slots: wave prefix sum of the per-lane counts, ONE LDS atomic per wave (a returning atomic per
+    // lane on one address serialises the whole block)
     int mine = __popc(wantbits);
-    int slot = mine ? atomicAdd(&n_todo, mine) : 0;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if ((threadIdx.x & 63) >= o) incl += t;
+    }
+    int wave_total = __shfl(incl, 63);
+    int wave_base = 0;
+    if ((threadIdx.x & 63) == 63 && wave_total) wave_base = atomicAdd(&n_todo, wave_total);
+    wave_base = __shfl(wave_base, 63);
+    int slot = wave_base + incl - mine;
 #pragma unroll
     for (int j = 0; j < GP_PER_THREAD; ++j)
         if ((wantbits >> j) & 1u) todo[slot++] = (uint16_t)(l0 + j);
@@ -464,18 +496,57 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const int32_t 
         const int y = (int)(p / w), x = (int)(p % w);
         const float ly = __fadd_rn((float)(y * step), offy[p]);  // coord + offsets
         const float lx = __fadd_rn((float)(x * step), offx[p]);
-        float sb = INFINITY, db = dinit;
+        // First index with the strictly smallest d = sqrt_rn(s).  sqrt_rn is monotone, and two floats whose ratio
+        // exceeds 1 + 2^-21 cannot round to the same square root, so the comparison of d reduces to a comparison
+        // of s except in a narrow near-tie band, where both roots are evaluated exactly.  sbest is the s of the
+        // current winner (a virtual candidate with d = 1e5, i.e. s = 1e10 exactly, when K > 20).
+        float sbest = sinit;
+        // sbest * (1 - 2^-20): at or below it, s is smaller beyond any tie of the rounded roots
+        float sclear = __fmul_rn(sinit, 0.99999904632568359375f);
         int id = idinit;
-        for (int k = 0; k < K; ++k) {
-            float2 c = ctr[k];
-            float dy = __fsub_rn(c.x, ly);
-            float dx = __fsub_rn(c.y, lx);
-            float s2 = __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
-            if (s2 < sb) {
-                sb = s2;
-                float dd = __fsqrt_rn(s2);
-                if (dd < db) { db = dd; id = k + 1; }
+        // Centres past K are padded with +inf (s = inf never wins).  Each batch is first run branch-free under the
+        // assumption "a near tie does not win"; if any lane of the wave met a near tie (rare), the batch is redone
+        // from the saved state with the exact comparison of the correctly rounded roots.
+        float2 c[GP_BATCH];
+#pragma unroll
+        for (int j = 0; j < GP_BATCH; ++j) c[j] = ctr[j];
+        for (int k0 = 0; k0 < K; k0 += GP_BATCH) {
+            float2 cn[GP_BATCH];
+#pragma unroll
+            for (int j = 0; j < GP_BATCH; ++j) cn[j] = ctr[k0 + GP_BATCH + j];      // next batch (padded), in flight
+            const float sbest0 = sbest, sclear0 = sclear;
+            const int id0 = id;
+            bool any_near = false;
+#pragma unroll
+            for (int j = 0; j < GP_BATCH; ++j) {
+                float dy = __fsub_rn(c[j].x, ly);
+                float dx = __fsub_rn(c[j].y, lx);
+                float s2 = __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
+                bool lt = s2 < sbest;
+                bool better = lt && s2 <= sclear;      // "lt" matters when sclear == sbest (zero / denormal sbest)
+                any_near = any_near || (lt && !better);
+                sbest = better ? s2 : sbest;
+                sclear = better ? __fmul_rn(s2, 0.99999904632568359375f) : sclear;
+                id = better ? k0 + j + 1 : id;
             }
+            if (__ballot(any_near)) {
+                if (any_near) {
+                    sbest = sbest0; sclear = sclear0; id = id0;
+#pragma unroll
+                    for (int j = 0; j < GP_BATCH; ++j) {
+                        float dy = __fsub_rn(c[j].x, ly);
+                        float dx = __fsub_rn(c[j].y, lx);
+                        float s2 = __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
+                        bool lt = s2 < sbest;
+                        bool better = lt && (s2 <= sclear || sqrt_rn_exact(s2) < sqrt_rn_exact(sbest));
+                        sbest = better ? s2 : sbest;
+                        sclear = better ? __fmul_rn(s2, 0.99999904632568359375f) : sclear;
+                        id = better ? k0 + j + 1 : id;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < GP_BATCH; ++j) c[j] = cn[j];
         }
         ids_tile[l] = (uint16_t)id;
     }
@@ -494,11 +565,14 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const int32_t 
     }
 }
 
+extern "C" int64_t emp_group_work_elems(int D, int cap) { return 2 * (int64_t)(D > 0 ? D : 1) * (cap + 2 * GP_BATCH); }
+
 extern "C" int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count, int cap,
                                 const float *offsets, int D, int h, int w, int step, const uint8_t *sem,
-                                uint32_t thing_mask, uint16_t *out_ids, void *stream)
+                                uint32_t thing_mask, float *work, uint16_t *out_ids, void *stream)
 {
-    EMP_REQUIRE(ctr_idx && ctr_count && offsets && out_ids, "group_pixels: null pointer");
+    EMP_REQUIRE(ctr_idx && ctr_count && offsets && out_ids && work, "group_pixels: null pointer");
+    EMP_REQUIRE((reinterpret_cast<uintptr_t>(work) & 7) == 0, "group_pixels: work must be 8-byte aligned");
     EMP_REQUIRE(cap >= 1 && cap <= EMP_MAX_CENTERS, "group_pixels: cap %d not in 1..%d", cap, EMP_MAX_CENTERS);
     EMP_REQUIRE(step == 1 || step == 4, "group_pixels: step must be 1 or 4");
     EMP_REQUIRE(D >= 0 && D <= 65535 && h > 0 && w > 0, "group_pixels: bad shape");
@@ -506,8 +580,11 @@ extern "C" int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count
     if (D == 0) return EMP_OK;
     int64_t hw = (int64_t)h * w;
     int gx = (int)emp_cdiv(hw, GP_TILE);
-    hipLaunchKernelGGL(group_pixels_kernel, dim3(gx, D), dim3(GP_THREADS), (size_t)cap * sizeof(float2), emp_stream(stream),
-                       ctr_idx, ctr_count, cap, offsets, h, w, step, sem, thing_mask, out_ids);
+    float2 *ctr_f = reinterpret_cast<float2 *>(work);
+    hipLaunchKernelGGL(group_centers_kernel, dim3(emp_grid((int64_t)D * (cap + 2 * GP_BATCH), 256, 1024)), dim3(256), 0,
+                       emp_stream(stream), ctr_idx, ctr_count, cap, w, step, D, ctr_f);
+    hipLaunchKernelGGL(group_pixels_kernel, dim3(gx, D), dim3(GP_THREADS), 0, emp_stream(stream), ctr_f, ctr_count,
+                       cap, offsets, h, w, step, sem, thing_mask, out_ids);
     EMP_CHECK_LAUNCH("emp_group_pixels");
     return EMP_OK;
 }

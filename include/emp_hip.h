@@ -93,10 +93,12 @@ int emp_find_centers(const float *hmp, int D, int h, int w, float thr, int k, in
  * sem (D, h, w) u8 or NULL: when given (same resolution as the offsets), pixels whose class bit is
  * clear in thing_mask are not voted on and get id 0 -- every consumer multiplies the ids by the
  * thing mask anyway (postprocess.py:221, engines.py:280-285), so results downstream are unchanged.
+ * work: emp_group_work_elems(D, cap) floats (the centres as fp32 coordinates, read with scalar loads).
  * out_ids (D, h, w) uint16.                                                                     */
+int64_t emp_group_work_elems(int D, int cap);
 int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count, int cap,
                      const float *offsets, int D, int h, int w, int step, const uint8_t *sem,
-                     uint32_t thing_mask, uint16_t *out_ids, void *stream);
+                     uint32_t thing_mask, float *work, uint16_t *out_ids, void *stream);
 
 /* ---- P4b + P5: instance cells -> panoptic labels -------------------------------------------
  * replaces get_instance_cells (nearest upsample)   engines.py:257-275

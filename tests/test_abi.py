@@ -36,7 +36,7 @@ def test_argument_validation_without_gpu():
     assert lib.emp_median_harden_stack(None, 4, 1, 16, 3, 0.5, None, None, None) == -1
     assert b'null' in lib.emp_last_error()
     assert lib.emp_find_centers(1, 1, 8, 8, 0.1, 99, 16, 1, 1, None) == -1
-    assert lib.emp_group_pixels(1, 1, 16, 1, 1, 8, 8, 3, None, 0, 1, None) == -1
+    assert lib.emp_group_pixels(1, 1, 16, 1, 1, 8, 8, 3, None, 0, 8, 1, None) == -1
     assert lib.emp_median_step(None, 4, 10, None, None) == -1
 
 
