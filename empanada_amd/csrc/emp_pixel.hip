@@ -307,19 +307,31 @@ __global__ __launch_bounds__(256) void find_centers_kernel(const float *__restri
             if (lane == 63 || x + VEC >= w) right = (live && x + VEC < w) ? img[q + VEC] : -INFINITY;
             v[0] = left;
             v[VEC + 1] = right;
-            if (!live) continue;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 float c = v[j + 1];
-                if (!(c > thr && c > 0.0f)) continue;
-                if (need_left && x + j > 0 && thresholded(v[j], thr) > c) continue;
-                if (need_right && x + j + 1 < w && thresholded(v[j + 2], thr) > c) continue;
-                // same necessary condition along the column (prunes the ridge of every blob down to its peak)
-                if (need_left && y > 0 && thresholded(img[q + j - w], thr) > c) continue;
-                if (need_right && y + 1 < h && thresholded(img[q + j + w], thr) > c) continue;
-                if (is_window_max(img, h, w, y, x + j, c, thr, k)) {
-                    int slot = atomicAdd(&out_count[d], 1);
-                    if (slot < cap) out_idx[(int64_t)d * cap + slot] = y * w + x + j;
+                bool cand = live && c > thr && c > 0.0f;
+                if (cand && need_left && x + j > 0 && thresholded(v[j], thr) > c) cand = false;
+                if (cand && need_right && x + j + 1 < w && thresholded(v[j + 2], thr) > c) cand = false;
+                // survivors of the in-row test (the ridge of every blob) are settled by the whole wave: the k x k
+                // window is fetched by k*k lanes at once and reduced with cross-lane maxima
+                unsigned long long todo = __ballot(cand);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int cy = __shfl(y, src), cx = __shfl(x, src) + j;
+                    const float cv = __shfl(c, src);
+                    float m = -INFINITY;
+                    for (int t = lane; t < k * k; t += 64) {
+                        int yy = cy - k / 2 + t / k, xx = cx - k / 2 + t % k;
+                        if (yy >= 0 && yy < h && xx >= 0 && xx < w) m = fmaxf(m, thresholded(img[(int64_t)yy * w + xx], thr));
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                    if (lane == src && !(m > cv)) {
+                        int slot = atomicAdd(&out_count[d], 1);
+                        if (slot < cap) out_idx[(int64_t)d * cap + slot] = cy * w + cx;
+                    }
                 }
             }
         }
