@@ -370,28 +370,31 @@ def bn_act_nhwc_(x, scale, shift, residual=None, relu=True):
     return x
 
 
-def yz_runs_along_x(table, value_u32, shape3d):
+def yz_runs_along_x(table, value_u32, shape3d, slice0=0):
     """yz stack run table + per-component value -> 3D runs along x of the dense (Z,Y,X) labelling:
-    (start3d int64, len int64, value int64) numpy arrays in raster order (emp_scatter_yz_u32 + row-run kernels)."""
+    (start3d int64, len int64, value int64) numpy arrays in raster order (emp_scatter_yz_u32 + row-run kernels).
+    The table may hold only the slices [slice0, slice0 + table.D) of the x axis (slice-sharded runs): the scatter
+    volume is then (Z, Y, table.D) wide and the starts are mapped into the full (Z, Y, X) frame."""
     require_gpu()
+    import numpy as np
     Z, Y, X = shape3d
+    Xl = table.D
     dev = table.r_start.device
-    vol = torch.zeros((Z, Y, X), dtype=torch.int32, device=dev).view(torch.uint32)
-    call('emp_scatter_yz_u32', _ptr(vol), Z, Y, X, _ptr(table.r_start), _ptr(table.r_len), _ptr(table.r_comp),
+    vol = torch.zeros((Z, Y, Xl), dtype=torch.int32, device=dev).view(torch.uint32)
+    call('emp_scatter_yz_u32', _ptr(vol), Z, Y, Xl, _ptr(table.r_start), _ptr(table.r_len), _ptr(table.r_comp),
          _ptr(table.c_slice), _ptr(value_u32), table.n_runs, stream())
     rows = torch.empty((Z * Y,), dtype=torch.int32, device=dev)
-    call('emp_runs_count', _ptr(vol), Z, Y, X, _ptr(rows), stream())
+    call('emp_runs_count', _ptr(vol), Z, Y, Xl, _ptr(rows), stream())
     offs = exclusive_scan_i32(rows)
     n = int(offs[-1].item())
     r_start = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
     r_len = torch.empty_like(r_start)
     r_val = torch.empty((max(n, 1),), dtype=torch.uint32, device=dev)
-    call('emp_runs_extract', _ptr(vol), Z, Y, X, _ptr(offs), _ptr(r_start), _ptr(r_len), _ptr(r_val), stream())
-    import numpy as np
+    call('emp_runs_extract', _ptr(vol), Z, Y, Xl, _ptr(offs), _ptr(r_start), _ptr(r_len), _ptr(r_val), stream())
     offs_h = offs.cpu().numpy().astype(np.int64)
-    st = r_start[:n].cpu().numpy().astype(np.int64)
+    st = r_start[:n].cpu().numpy().astype(np.int64)          # y * Xl + x inside plane z
     ln = r_len[:n].cpu().numpy().astype(np.int64)
     val = r_val[:n].cpu().numpy().astype(np.int64)
     row = np.searchsorted(offs_h, np.arange(n), side='right') - 1          # row = z * Y + y
-    z = row // Y
-    return st + z * (Y * X), ln, val
+    x = st % Xl
+    return row * X + slice0 + x, ln, val

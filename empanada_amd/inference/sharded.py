@@ -21,11 +21,11 @@ import torch
 import torch.distributed as dist
 
 from .. import _hip
-from .patterns import chain_from_tables, tables_from_stack
+from .patterns import _assemble_trackers, chain_from_tables, merge_partial_trackers, tables_from_stack
 from .postprocess import centers_batched
 
 __all__ = ['shard_bounds', 'merge_rank_tables', 'filter_labels', 'gather_tables_and_chain', 'sharded_panoptic_stack',
-           'sharded_tables', 'fill_slab', 'sharded_stack_volume']
+           'sharded_tables', 'fill_slab', 'sharded_stack_volume', 'partial_trackers', 'sharded_track_plane']
 
 
 def _world():
@@ -115,24 +115,26 @@ def filter_labels(host, comp_final, min_size=None, min_span=None):
 
 
 def gather_tables_and_chain(local_host, n_local, labels, thing_list, label_divisor, merge_iou_thr=0.25,
-                            merge_ioa_thr=0.25, min_size=None, min_span=None, group=None):
+                            merge_ioa_thr=0.25, min_size=None, min_span=None, group=None, return_first_seen=False):
     """Steps 4-5 of the module docstring.  Every rank passes its local tables (own slices + halo); rank 0 merges
     them, runs the chain over the whole axis and the size/span filters, and every rank receives the final label
     of each of its own components (0 = filtered out; halo components get 0)."""
     rank, world = _world()
     if world == 1:
-        final, _ = chain_from_tables(local_host, n_local, labels, thing_list, label_divisor, merge_iou_thr,
-                                     merge_ioa_thr)
-        return filter_labels(local_host, final, min_size, min_span)
+        final, first_seen = chain_from_tables(local_host, n_local, labels, thing_list, label_divisor, merge_iou_thr,
+                                              merge_ioa_thr)
+        final = filter_labels(local_host, final, min_size, min_span)
+        return (final, first_seen) if return_first_seen else final
     gathered = [None] * world
     dist.all_gather_object(gathered, (local_host, int(n_local)), group=group)
     result = [None]
+    first_seen = None
     if rank == 0:
         tables = [g[0] for g in gathered]
         counts = np.array([g[1] for g in gathered], dtype=np.int64)
         merged, own_index = merge_rank_tables(tables, counts)
-        final, _ = chain_from_tables(merged, int(counts.sum()), labels, thing_list, label_divisor, merge_iou_thr,
-                                     merge_ioa_thr)
+        final, first_seen = chain_from_tables(merged, int(counts.sum()), labels, thing_list, label_divisor,
+                                              merge_iou_thr, merge_ioa_thr)
         final = filter_labels(merged, final, min_size, min_span)
         per_rank = []
         for idx in own_index:
@@ -141,7 +143,8 @@ def gather_tables_and_chain(local_host, n_local, labels, thing_list, label_divis
             per_rank.append(v)
         result = [per_rank]
     dist.broadcast_object_list(result, src=0, group=group)
-    return result[0][rank]
+    final = result[0][rank]
+    return (final, first_seen) if return_first_seen else final
 
 
 # ----------------------------------------------------------------------------- device side
@@ -208,3 +211,33 @@ def sharded_stack_volume(pan_local, labels, thing_list, label_divisor, merge_iou
     final = gather_tables_and_chain(host, pan_local.shape[0], list(labels), list(thing_list), label_divisor,
                                     merge_iou_thr, merge_ioa_thr, min_size, min_span, group)
     return fill_slab(table, final, tuple(pan_local.shape))
+
+
+# ----------------------------------------------------------------------------- orthoplane: trackers per plane
+def partial_trackers(table, host, final_local, axis_name, shape3d, slice0, labels, label_divisor):
+    """The rank's share of one plane's trackers: 3D run lists of its own slices (global slice = slice0 + local),
+    instances in ascending label order.  Halo components carry label 0 and are skipped."""
+    return _assemble_trackers(table, np.asarray(final_local, dtype=np.int64), host['c_slice'], host['c_cls'],
+                              host['c_box'], None, axis_name, shape3d, list(labels), label_divisor, slice0=slice0)
+
+
+def sharded_track_plane(pan_local, axis_name, shape3d, slice0, labels, thing_list, label_divisor, merge_iou_thr=0.25,
+                        merge_ioa_thr=0.25, group=None):
+    """Orthoplane mode, one plane: every rank passes the panoptic labels of its contiguous block of slices
+    (global index of the first one = slice0).  Steps: local runs / CC / halo overlaps, chain over the whole axis on
+    rank 0, per-rank partial trackers (the O(#runs) assembly is sharded too), all-gather of the partial per-instance
+    3D RLE tables -- the collective SURVEY 8(e) calls "Collective 2" -- and the stitch on rank 0.
+    Returns the plane's finished trackers on rank 0 (None on the other ranks)."""
+    rank, world = _world()
+    labels, thing_list = list(labels), list(thing_list)
+    table, host = sharded_tables(pan_local, labels, thing_list, label_divisor, group)
+    final, first_seen = gather_tables_and_chain(host, pan_local.shape[0], labels, thing_list, label_divisor,
+                                                merge_iou_thr, merge_ioa_thr, group=group, return_first_seen=True)
+    part = partial_trackers(table, host, final, axis_name, shape3d, slice0, labels, label_divisor)
+    if world == 1:
+        return merge_partial_trackers([part], first_seen, axis_name, shape3d, labels, label_divisor)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, part, group=group)
+    if rank != 0:
+        return None
+    return merge_partial_trackers(gathered, first_seen, axis_name, shape3d, labels, label_divisor)

@@ -295,3 +295,46 @@ def test_sharded_path_world1_equals_tracker_path():
     got = sharded.sharded_stack_volume(pan2, [1], [1], 20000, 0.25, 0.25, min_size=300, min_span=4).cpu().numpy()
     assert exp.max() > 0 and len(np.unique(exp)) > 5
     np.testing.assert_array_equal(got, exp)
+
+
+def test_partial_trackers_stitch_equals_whole_axis():
+    """slice-sharded orthoplane tracking, all three axes, without the collectives: two 'virtual ranks' build their
+    tables (with halo), the tables are merged and chained as on rank 0, each block assembles its partial trackers
+    and the stitch reproduces track_stack over the whole axis (which the reference fixtures pin)."""
+    from empanada_amd.inference import patterns as PA
+    from empanada_amd.inference import sharded
+    from empanada_amd.inference.postprocess import panoptic_stack
+    shape = (30, 40, 36)
+    lab, cls = SY.planted_labels(shape, fill=0.2, rmin=4, rmax=9, seed=77, n_classes=3)
+    thing, labels = [1, 2], [1, 2, 3]
+    for name, ax in (('xy', 0), ('xz', 1), ('yz', 2)):
+        heads = SY.planted_heads(lab, cls, name, n_classes=3, seed=13)
+        pan, _ = panoptic_stack(heads['sem'].cuda(), heads['ctr_hmp'].cuda(), heads['offsets'].cuda(),
+                                thing_list=thing, label_divisor=1000, stuff_area=16, void_label=0, nms_threshold=0.1,
+                                nms_kernel=7, confidence_thr=0.5, median_kernel_size=3, coarse_boundaries=False)
+        whole = PA.track_stack(pan, name, shape, labels, thing, 1000, 0.25, 0.25)
+        D = pan.shape[0]
+        for cut in (D // 2, 7):
+            bounds = [0, cut, D]
+            tabs, hosts = [], []
+            for r in range(2):
+                lo, hi = bounds[r], bounds[r + 1]
+                ext = pan[lo:hi + 1] if r == 0 else pan[lo:hi]
+                t, h = PA.tables_from_stack(ext.contiguous(), labels, thing, 1000)
+                tabs.append(t); hosts.append(h)
+            counts = np.array([cut, D - cut])
+            merged, own = sharded.merge_rank_tables(hosts, counts)
+            final, first_seen = PA.chain_from_tables(merged, D, labels, thing, 1000, 0.25, 0.25)
+            parts = []
+            for r in range(2):
+                fl = np.zeros(len(own[r]), dtype=np.int64)
+                fl[own[r] >= 0] = final[own[r][own[r] >= 0]]
+                parts.append(sharded.partial_trackers(tabs[r], hosts[r], fl, name, shape, bounds[r], labels, 1000))
+            stitched = PA.merge_partial_trackers(parts, first_seen, name, shape, labels, 1000)
+            for a, b in zip(stitched, whole):
+                assert a.class_id == b.class_id
+                assert_instances_equal(a.instances, b.instances)
+        # world = 1 through the public entry point
+        solo = sharded.sharded_track_plane(pan, name, shape, 0, labels, thing, 1000)
+        for a, b in zip(solo, whole):
+            assert_instances_equal(a.instances, b.instances)

@@ -164,3 +164,90 @@ def test_host_chain_against_reference_goldens():
             final, _ = chain_from_tables(host, pans.shape[0], labels, thing, DIV, 0.25, 0.25)
             np.testing.assert_array_equal(paint(maps, final).reshape(pans.shape), g[f'p{i}_{name}_bwd'],
                                           err_msg=f'{i} {name}')
+
+
+# ------------------------------------------------------------------------------------------------ orthoplane
+class _FakeTable:
+    """CPU twin of _hip.RunTable (torch tensors on the host) for the numpy assembly code."""
+
+
+def cpu_run_table(pan_shape, comp_maps, host):
+    D, H, W = pan_shape
+    rs, rl, rc = [], [], []
+    for d in range(D):
+        cm = comp_maps[d].reshape(H, W)
+        for y in range(H):
+            row = cm[y]
+            x = 0
+            while x < W:
+                if row[x] >= 0:
+                    x1 = x
+                    while x1 < W and row[x1] == row[x]:
+                        x1 += 1
+                    rs.append(y * W + x); rl.append(x1 - x); rc.append(int(row[x]))
+                    x = x1
+                else:
+                    x += 1
+    t = _FakeTable()
+    t.D, t.H, t.W = D, H, W
+    t.r_start = torch.tensor(rs, dtype=torch.int32)
+    t.r_len = torch.tensor(rl, dtype=torch.int32)
+    t.r_comp = torch.tensor(rc, dtype=torch.int32)
+    t.c_slice = torch.from_numpy(host['c_slice'].astype(np.int32))
+    t.n_runs, t.n_comp = len(rs), len(host['c_slice'])
+    return t
+
+
+def _worker_plane(rank, world, port, bounds, axis_name, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        pan = make_stack(seed=5)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        ext = pan[lo:hi + 1] if rank + 1 < world else pan[lo:hi]
+
+        def fake_tables(pan_local, labels, thing_list, label_divisor, group=None):
+            host, maps = cpu_tables(ext, list(labels), list(thing_list))
+            return cpu_run_table(ext.shape, maps, host), host
+        sharded.sharded_tables = fake_tables
+        shape3d = pan.shape if axis_name == 'xy' else (pan.shape[1], pan.shape[0], pan.shape[2])
+        trs = sharded.sharded_track_plane(torch.zeros((hi - lo, 1, 1)), axis_name, shape3d, lo, [1, 2], [1], DIV)
+        q.put((rank, None if trs is None else [{k: (v['box'], v['starts'], v['runs']) for k, v in t.instances.items()}
+                                                for t in trs]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('axis_name', ['xy', 'xz'])
+def test_two_rank_plane_trackers_equal_single_rank(axis_name):
+    """sharded_track_plane over gloo (tables -> rank-0 chain -> partial trackers -> all_gather_object -> stitch)
+    against the same functions on one rank.  The device half is replaced by its numpy twin (no GPU here); the yz
+    scatter path is covered on the GPU (tests/test_pipeline_gpu.py::test_partial_trackers_stitch...)."""
+    from empanada_amd.inference.patterns import _assemble_trackers
+    pan = make_stack(seed=5)
+    shape3d = pan.shape if axis_name == 'xy' else (pan.shape[1], pan.shape[0], pan.shape[2])
+    host, maps = cpu_tables(pan, [1, 2], [1])
+    final, first_seen = chain_from_tables(host, pan.shape[0], [1, 2], [1], DIV, 0.25, 0.25)
+    table = cpu_run_table(pan.shape, maps, host)
+    whole = _assemble_trackers(table, final, host['c_slice'], host['c_cls'], host['c_box'], first_seen, axis_name,
+                               shape3d, [1, 2], DIV)
+    bounds = np.array([0, 6, pan.shape[0]])
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_plane, args=(r, 2, port, bounds, axis_name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] is None
+    assert sum(len(t.instances) for t in whole) > 3
+    for tr, g in zip(whole, got[0]):
+        assert list(tr.instances.keys()) == list(g.keys())
+        for k, a in tr.instances.items():
+            assert tuple(a['box']) == tuple(g[k][0])
+            np.testing.assert_array_equal(a['starts'], g[k][1])
+            np.testing.assert_array_equal(a['runs'], g[k][2])
