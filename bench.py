@@ -132,87 +132,103 @@ class Pipeline:
         return vol
 
 
-def build_inputs_ortho(S, device):
+def build_inputs_ortho(S, device, rank=0, world=1):
+    """cubic volume; every rank holds the EM slices and planted heads of its own contiguous block per plane"""
     from empanada_amd import synthetic as SY
+    from empanada_amd.inference.sharded import shard_bounds
     shape = (S, S, S)
-    vol = torch.from_numpy(SY.em_volume(shape, seed=1234)).to(device)
+    b = shard_bounds(S, world)
+    lo, hi = int(b[rank]), int(b[rank + 1])
+    em = SY.em_volume(shape, seed=1234)
     lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321)
-    heads = {}
-    for axis in ('xy', 'xz', 'yz'):
+    heads, stacks = {}, {}
+    for axis, ax in (('xy', 0), ('xz', 1), ('yz', 2)):
+        stacks[axis] = torch.from_numpy(np.ascontiguousarray(np.moveaxis(em, ax, 0)[lo:hi])).to(device)
         parts = {'sem': [], 'ctr_hmp': [], 'offsets': []}
-        for s in range(0, S, 64):
-            h = SY.planted_heads(lab, cls, axis, device=device, slices=slice(s, min(S, s + 64)), seed=99 + s)
+        for s in range(lo, hi, 64):
+            h = SY.planted_heads(lab, cls, axis, device=device, slices=slice(s, min(hi, s + 64)), seed=99 + s)
             for k in parts:
                 parts[k].append(h[k])
         heads[axis] = {k: torch.cat(v, dim=0).contiguous() for k, v in parts.items()}
-    return vol, heads, int(cls.shape[0] - 1)
+    return stacks, heads, int(cls.shape[0] - 1), lo
 
 
-def orthoplane_step(pipe, vol, heads, host_out, stages):
-    """One pass of BASELINE configs[2]: three stacks (xy, xz, yz) -> trackers -> filters -> instance consensus
-    -> filters -> labelled volume in pinned host memory (scripts/pdl_inference3d.py:110-233 in orthoplane mode)."""
-    from empanada_amd.inference import filters
-    from empanada_amd.inference import patterns as PA
-    from empanada_amd.inference.postprocess import panoptic_stack
-    shape3d = tuple(vol.shape)
+def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages):
+    """One pass of BASELINE configs[2]: three slice-sharded stacks (xy, xz, yz) -> trackers stitched on rank 0 ->
+    filters -> instance consensus -> filters -> labelled volume in pinned host memory
+    (scripts/pdl_inference3d.py:110-233 in orthoplane mode)."""
+    from empanada_amd.inference import sharded
     trackers = {}
     chk = 0
-    for axis, perm in (('xy', (0, 1, 2)), ('xz', (1, 0, 2)), ('yz', (2, 0, 1))):
+    for axis in ('xy', 'xz', 'yz'):
         t0 = time.perf_counter()
-        stack = vol.permute(*perm).contiguous()
-        prob, c = pipe.forward(stack)
+        prob, c = pipe.forward(stacks[axis])
         chk = chk + c
         h = heads[axis]
-        pan, _ = panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False, **ENGINE)
+        pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False, **ENGINE)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        trs = PA.track_stack(pan, axis, shape3d, [1], ENGINE['thing_list'], ENGINE['label_divisor'], **MATCH)
-        for tr in trs:
-            filters.remove_small_objects(tr, FILTERS['min_size'])
-            filters.remove_pancakes(tr, FILTERS['min_span'])
-        trackers[axis] = trs
+        trackers[axis] = sharded.sharded_track_plane(pan, axis, shape3d, slice0, [1], ENGINE['thing_list'],
+                                                     ENGINE['label_divisor'], **MATCH)
         t2 = time.perf_counter()
         stages[f'{axis}_forward_and_pixels'] = stages.get(f'{axis}_forward_and_pixels', 0) + t1 - t0
         stages[f'{axis}_tracking'] = stages.get(f'{axis}_tracking', 0) + t2 - t1
-    t0 = time.perf_counter()
-    con = PA.create_instance_consensus(PA.get_axis_trackers_by_class(trackers, 1), 2, 0.75, False)
-    filters.remove_small_objects(con, FILTERS['min_size'])
-    filters.remove_pancakes(con, FILTERS['min_span'])
-    t1 = time.perf_counter()
-    out = PA.fill_volume_device(shape3d, [con])
-    host_out.copy_(out.view(torch.int32), non_blocking=True)
-    torch.cuda.synchronize()
-    stages['consensus'] = stages.get('consensus', 0) + t1 - t0
-    stages['fill_to_host'] = stages.get('fill_to_host', 0) + time.perf_counter() - t1
-    return chk, len(con.instances)
+    n_found = 0
+    if trackers['xy'] is not None:                   # rank 0 holds the stitched trackers
+        t0 = time.perf_counter()
+        cons, vols = sharded.consensus_volume(trackers, shape3d, [1], ENGINE['thing_list'], 2, 0.75, False,
+                                              FILTERS['min_size'], FILTERS['min_span'])
+        t1 = time.perf_counter()
+        host_out.copy_(vols[1].view(torch.int32), non_blocking=True)
+        torch.cuda.synchronize()
+        stages['consensus_and_fill'] = stages.get('consensus_and_fill', 0) + t1 - t0
+        stages['to_host'] = stages.get('to_host', 0) + time.perf_counter() - t1
+        n_found = len(cons[1].instances)
+    return chk, n_found
 
 
-def main_orthoplane(args, device):
+def main_orthoplane(args, device, rank, world):
+    import torch.distributed as dist
     S = args.size
-    log(f'orthoplane: building inputs {S}^3')
-    vol, heads, n_obj = build_inputs_ortho(S, device)
+    log(f'orthoplane: building inputs {S}^3 (rank {rank}/{world})')
+    stacks, heads, n_obj, slice0 = build_inputs_ortho(S, device, rank, world)
     log(f'inputs ready ({n_obj} planted objects)')
     pipe = Pipeline(args, device)
-    host_out = torch.empty((S, S, S), dtype=torch.int32).pin_memory()
+    shape3d = (S, S, S)
+    host_out = torch.empty(shape3d, dtype=torch.int32).pin_memory() if rank == 0 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for i in range(args.warmup):
-        orthoplane_step(pipe, vol, heads, host_out, {})
+        orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, {})
         log(f'warmup {i} done')
-    torch.cuda.synchronize()
+    barrier()
     stages = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        chk, n_found = orthoplane_step(pipe, vol, heads, host_out, stages)
-    torch.cuda.synchronize()
+        chk, n_found = orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages)
+    barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
     res = {
         'metric': 'Mvox/s end-to-end 3D panoptic inference (incl. consensus); PQ vs CPU ref',
-        'value': round(float(S) ** 3 * args.steps / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': 1, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else args.dtype,
-        'data': 'synthetic',
+        'value': round(float(S) ** 3 * args.steps / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f32' if args.dtype == 'fp32' else args.dtype, 'data': 'synthetic',
         'config': {'workload': f'orthoplane (xy/xz/yz) inference + instance consensus, {S}^3 uint8 volume, '
                                f'PanopticDeepLab/ResNet-50 C=1 forward on every slice of every plane + HIP '
-                               f'post-processing on planted heads, {n_obj} planted objects',
+                               f'post-processing on planted heads, {n_obj} planted objects, slices sharded over '
+                               f'{world} rank(s)',
                    'mode': 'orthoplane', 'objects_found': int(n_found)},
         'stages_s_per_step': {k: round(v / args.steps, 4) for k, v in stages.items()},
     }
@@ -297,8 +313,10 @@ def main():
     torch.backends.cudnn.benchmark = True
 
     if args.mode == 'orthoplane':
-        assert world == 1, "orthoplane bench mode is single-GPU this round"
-        return main_orthoplane(args, device)
+        main_orthoplane(args, device, rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     D, S = args.depth, args.size
     log(f'building inputs {D}x{S}x{S}')
     vol, heads, n_obj = build_inputs(D, S, device, seed_offset=rank)

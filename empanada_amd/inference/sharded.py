@@ -25,7 +25,8 @@ from .patterns import _assemble_trackers, chain_from_tables, merge_partial_track
 from .postprocess import centers_batched
 
 __all__ = ['shard_bounds', 'merge_rank_tables', 'filter_labels', 'gather_tables_and_chain', 'sharded_panoptic_stack',
-           'sharded_tables', 'fill_slab', 'sharded_stack_volume', 'partial_trackers', 'sharded_track_plane']
+           'sharded_tables', 'fill_slab', 'sharded_stack_volume', 'partial_trackers', 'sharded_track_plane',
+           'consensus_volume']
 
 
 def _world():
@@ -241,3 +242,35 @@ def sharded_track_plane(pan_local, axis_name, shape3d, slice0, labels, thing_lis
     if rank != 0:
         return None
     return merge_partial_trackers(gathered, first_seen, axis_name, shape3d, labels, label_divisor)
+
+
+def consensus_volume(trackers_by_axis, shape3d, labels, thing_list, pixel_vote_thr=2, cluster_iou_thr=0.75,
+                     bypass=False, min_size=None, min_span=None):
+    """Orthoplane mode, last step, on the rank that holds the stitched trackers (rank 0): per-plane filters,
+    instance / semantic consensus per class, filters again, fill (scripts/pdl_inference3d.py:200-233).
+    trackers_by_axis: {'xy': [tracker per label], 'xz': [...], 'yz': [...]}.
+    Returns ({class: consensus tracker}, {class: labelled (Z,Y,X) device volume, uint32 for things / uint8 stuff})."""
+    from . import filters
+    from .patterns import (create_instance_consensus, create_semantic_consensus, fill_volume_device,
+                           get_axis_trackers_by_class)
+    for trs in trackers_by_axis.values():
+        for tr in trs:
+            if min_size is not None:
+                filters.remove_small_objects(tr, min_size)
+            if min_span is not None:
+                filters.remove_pancakes(tr, min_span)
+    cons, vols = {}, {}
+    for class_id in labels:
+        cts = get_axis_trackers_by_class(trackers_by_axis, class_id)
+        if class_id in thing_list:
+            con = create_instance_consensus(cts, pixel_vote_thr, cluster_iou_thr, bypass)
+            if min_size is not None:
+                filters.remove_small_objects(con, min_size)
+            if min_span is not None:
+                filters.remove_pancakes(con, min_span)
+            vols[class_id] = fill_volume_device(shape3d, [con])
+        else:
+            con = create_semantic_consensus(cts, pixel_vote_thr)
+            vols[class_id] = fill_volume_device(shape3d, [con], dtype=torch.uint8)
+        cons[class_id] = con
+    return cons, vols
