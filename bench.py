@@ -97,6 +97,7 @@ class Pipeline:
         self.device = device
         self.batch = args.batch
         self.timers = {}
+        self.post_stream = torch.cuda.Stream(device=device)
 
     @torch.no_grad()
     def forward(self, vol):
@@ -160,19 +161,44 @@ def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages):
     from empanada_amd.inference import sharded
     trackers = {}
     chk = 0
-    for axis in ('xy', 'xz', 'yz'):
-        t0 = time.perf_counter()
-        prob, c = pipe.forward(stacks[axis])
-        chk = chk + c
-        h = heads[axis]
-        pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False, **ENGINE)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        trackers[axis] = sharded.sharded_track_plane(pan, axis, shape3d, slice0, [1], ENGINE['thing_list'],
-                                                     ENGINE['label_divisor'], **MATCH)
-        t2 = time.perf_counter()
-        stages[f'{axis}_forward_and_pixels'] = stages.get(f'{axis}_forward_and_pixels', 0) + t1 - t0
-        stages[f'{axis}_tracking'] = stages.get(f'{axis}_tracking', 0) + t2 - t1
+    # Two HIP streams.  The forward of plane p+1 is queued (default stream) as soon as the device tables of plane p
+    # are on the host; the host half of plane p (label-propagation chain, tracker assembly) and its device work
+    # (D2H copies, yz scatter) run on the post-processing stream meanwhile, so neither side waits for the other.
+    # (Queuing all three forwards up front does not work: ~14k launches exceed the HIP queue and the host blocks.)
+    post = pipe.post_stream
+    planes = ('xy', 'xz', 'yz')
+    prob, c = pipe.forward(stacks['xy'])
+    chk = chk + c
+    ev = torch.cuda.Event()
+    ev.record()
+    with torch.cuda.stream(post):
+        for i, axis in enumerate(planes):
+            t0 = time.perf_counter()
+            post.wait_event(ev)
+            h = heads[axis]
+            pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False,
+                                                 **ENGINE)
+            table, host = sharded.sharded_tables(pan, [1], ENGINE['thing_list'], ENGINE['label_divisor'])
+            t1 = time.perf_counter()
+            if i + 1 < len(planes):
+                with torch.cuda.stream(torch.cuda.default_stream()):
+                    prob, c = pipe.forward(stacks[planes[i + 1]])
+                    chk = chk + c
+                    ev = torch.cuda.Event()
+                    ev.record()
+            t2 = time.perf_counter()
+            trackers[axis] = sharded.finish_plane(table, host, pan.shape[0], axis, shape3d, slice0, [1],
+                                                  ENGINE['thing_list'], ENGINE['label_divisor'], **MATCH)
+            stages[f'{axis}_wait_forward_pixels_tables'] = stages.get(f'{axis}_wait_forward_pixels_tables', 0) + t1 - t0
+            stages[f'{axis}_enqueue_next_forward'] = stages.get(f'{axis}_enqueue_next_forward', 0) + t2 - t1
+            stages[f'{axis}_tracking'] = stages.get(f'{axis}_tracking', 0) + time.perf_counter() - t2
+        n_found = _orthoplane_finish(trackers, shape3d, host_out, stages)
+    torch.cuda.current_stream().wait_stream(post)
+    return chk, n_found
+
+
+def _orthoplane_finish(trackers, shape3d, host_out, stages):
+    from empanada_amd.inference import sharded
     n_found = 0
     if trackers['xy'] is not None:                   # rank 0 holds the stitched trackers
         t0 = time.perf_counter()
@@ -184,7 +210,7 @@ def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages):
         stages['consensus_and_fill'] = stages.get('consensus_and_fill', 0) + t1 - t0
         stages['to_host'] = stages.get('to_host', 0) + time.perf_counter() - t1
         n_found = len(cons[1].instances)
-    return chk, n_found
+    return n_found
 
 
 def main_orthoplane(args, device, rank, world):

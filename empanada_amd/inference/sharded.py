@@ -25,7 +25,7 @@ from .patterns import _assemble_trackers, chain_from_tables, merge_partial_track
 from .postprocess import centers_batched
 
 __all__ = ['shard_bounds', 'merge_rank_tables', 'filter_labels', 'gather_tables_and_chain', 'sharded_panoptic_stack',
-           'sharded_tables', 'fill_slab', 'sharded_stack_volume', 'partial_trackers', 'sharded_track_plane',
+           'sharded_tables', 'fill_slab', 'sharded_stack_volume', 'partial_trackers', 'sharded_track_plane', 'finish_plane',
            'consensus_volume']
 
 
@@ -222,18 +222,15 @@ def partial_trackers(table, host, final_local, axis_name, shape3d, slice0, label
                               host['c_box'], None, axis_name, shape3d, list(labels), label_divisor, slice0=slice0)
 
 
-def sharded_track_plane(pan_local, axis_name, shape3d, slice0, labels, thing_list, label_divisor, merge_iou_thr=0.25,
-                        merge_ioa_thr=0.25, group=None):
-    """Orthoplane mode, one plane: every rank passes the panoptic labels of its contiguous block of slices
-    (global index of the first one = slice0).  Steps: local runs / CC / halo overlaps, chain over the whole axis on
-    rank 0, per-rank partial trackers (the O(#runs) assembly is sharded too), all-gather of the partial per-instance
-    3D RLE tables -- the collective SURVEY 8(e) calls "Collective 2" -- and the stitch on rank 0.
-    Returns the plane's finished trackers on rank 0 (None on the other ranks)."""
+def finish_plane(table, host, n_local, axis_name, shape3d, slice0, labels, thing_list, label_divisor,
+                 merge_iou_thr=0.25, merge_ioa_thr=0.25, group=None):
+    """Host half of sharded_track_plane (everything after the device tables exist): chain on rank 0, partial
+    trackers, all-gather of the RLE tables, stitch.  Split out so that a driver can queue the next plane's forward
+    on the GPU before calling it."""
     rank, world = _world()
     labels, thing_list = list(labels), list(thing_list)
-    table, host = sharded_tables(pan_local, labels, thing_list, label_divisor, group)
-    final, first_seen = gather_tables_and_chain(host, pan_local.shape[0], labels, thing_list, label_divisor,
-                                                merge_iou_thr, merge_ioa_thr, group=group, return_first_seen=True)
+    final, first_seen = gather_tables_and_chain(host, n_local, labels, thing_list, label_divisor, merge_iou_thr,
+                                                merge_ioa_thr, group=group, return_first_seen=True)
     part = partial_trackers(table, host, final, axis_name, shape3d, slice0, labels, label_divisor)
     if world == 1:
         return merge_partial_trackers([part], first_seen, axis_name, shape3d, labels, label_divisor)
@@ -242,6 +239,18 @@ def sharded_track_plane(pan_local, axis_name, shape3d, slice0, labels, thing_lis
     if rank != 0:
         return None
     return merge_partial_trackers(gathered, first_seen, axis_name, shape3d, labels, label_divisor)
+
+
+def sharded_track_plane(pan_local, axis_name, shape3d, slice0, labels, thing_list, label_divisor, merge_iou_thr=0.25,
+                        merge_ioa_thr=0.25, group=None):
+    """Orthoplane mode, one plane: every rank passes the panoptic labels of its contiguous block of slices
+    (global index of the first one = slice0).  Steps: local runs / CC / halo overlaps, chain over the whole axis on
+    rank 0, per-rank partial trackers (the O(#runs) assembly is sharded too), all-gather of the partial per-instance
+    3D RLE tables -- the collective SURVEY 8(e) calls "Collective 2" -- and the stitch on rank 0.
+    Returns the plane's finished trackers on rank 0 (None on the other ranks)."""
+    table, host = sharded_tables(pan_local, list(labels), list(thing_list), label_divisor, group)
+    return finish_plane(table, host, pan_local.shape[0], axis_name, shape3d, slice0, labels, thing_list,
+                        label_divisor, merge_iou_thr, merge_ioa_thr, group)
 
 
 def consensus_volume(trackers_by_axis, shape3d, labels, thing_list, pixel_vote_thr=2, cluster_iou_thr=0.75,
