@@ -51,6 +51,9 @@ SIGNATURES = {
     'emp_runs_label_work_elems': (_L, [_L]),
     'emp_runs_label': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _L, _U32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'emp_runs_overlap_next': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P, _L, _P, _P]),
+    'emp_rle_decode': (_I, [_P, _P, _P, _L, _P, _P]),
+    'emp_rle_encode_work_elems': (_L, [_L]),
+    'emp_rle_encode': (_I, [_P, _L, _P, _P, _P, _P, _P]),
     'emp_box_pairs': (_I, [_P, _L, _P, _L, _I, _P, _P, _I, _P, _L, _P, _P]),
     'emp_rle_pair_intersections': (_I, [_P, _P, _P, _P, _L, _P, _P]),
     'emp_sort_work_bytes': (_L, [_L]),
@@ -398,3 +401,30 @@ def yz_runs_along_x(table, value_u32, shape3d, slice0=0):
     row = np.searchsorted(offs_h, np.arange(n), side='right') - 1          # row = z * Y + y
     x = st % Xl
     return row * X + slice0 + x, ln, val
+
+
+def rle_decode(starts, runs):
+    """device int64 (starts, runs) -> int64 indices (emp_rle_decode); offsets via torch.cumsum (plumbing)."""
+    require_gpu()
+    n = starts.numel()
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64, device=starts.device)
+    csum = torch.cumsum(runs, 0)
+    off = (csum - runs).contiguous()
+    out = torch.empty((int(csum[-1].item()),), dtype=torch.int64, device=starts.device)
+    call('emp_rle_decode', _ptr(starts.contiguous()), _ptr(runs.contiguous()), _ptr(off), n, _ptr(out), stream())
+    return out
+
+
+def rle_encode(indices):
+    """device int64 ascending indices -> (starts, runs) int64 (emp_rle_encode)."""
+    require_gpu()
+    n = indices.numel()
+    dev = indices.device
+    work = torch.empty((query('emp_rle_encode_work_elems', n),), dtype=torch.int32, device=dev)
+    st = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    rn = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    call('emp_rle_encode', _ptr(indices.contiguous()), n, _ptr(work), _ptr(st), _ptr(rn), _ptr(cnt), stream())
+    k = int(cnt.item())
+    return st[:k], rn[:k]

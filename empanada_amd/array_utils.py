@@ -22,6 +22,10 @@ __all__ = [
 ]
 
 
+def _dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
 # ----------------------------------------------------------------------------- host bookkeeping
 def take(array, indices, axis=0):
     """array_utils.py:6-23"""
@@ -49,26 +53,25 @@ def merge_boxes(box1, box2):
 
 def box_pairs(boxes1, boxes2=None):
     """Pairs of boxes with strictly positive intersection (array_utils.py:144-172), row-major.
-    Returns rows, cols, ious (fp64), intersections (int64).  O(n*m) integer screening on the host
-    over the O(#objects) box tables (the reference runs it in numba)."""
+    Returns rows, cols, ious (fp64), intersections (int64).  Which pairs intersect is decided on the GPU
+    (emp_box_pairs); the IoU of the surviving pairs is integer arithmetic on the host."""
     boxes1 = np.asarray(boxes1, dtype=np.int64)
     boxes2 = boxes1 if boxes2 is None else np.asarray(boxes2, dtype=np.int64)
     if boxes1.size == 0 or boxes2.size == 0:
         e = np.zeros(0, dtype=np.int64)
         return e, e, np.zeros(0), e
+    _hip.require_gpu()
+    if max(int(np.abs(boxes1).max()), int(np.abs(boxes2).max())) >= 2 ** 31:
+        raise ValueError("box coordinates must fit in int32")
+    pairs = _hip.box_pairs(_dev(boxes1, np.int32), _dev(boxes2, np.int32)).cpu().numpy().astype(np.int64)
+    order = np.lexsort((pairs[:, 1], pairs[:, 0]))                  # row-major like the reference's nested loops
+    rows, cols = pairs[order, 0], pairs[order, 1]
     nd = boxes1.shape[1] // 2
-    inter = np.ones((len(boxes1), len(boxes2)), dtype=np.int64)
-    a1 = np.ones(len(boxes1), dtype=np.int64)
-    a2 = np.ones(len(boxes2), dtype=np.int64)
-    for i in range(nd):
-        lo = np.maximum(boxes1[:, None, i], boxes2[None, :, i])
-        hi = np.minimum(boxes1[:, None, i + nd], boxes2[None, :, i + nd])
-        inter *= np.maximum(0, hi - lo)
-        a1 *= boxes1[:, i + nd] - boxes1[:, i]
-        a2 *= boxes2[:, i + nd] - boxes2[:, i]
-    rows, cols = np.nonzero(inter > 0)
-    it = inter[rows, cols]
-    return rows, cols, it / (a1[rows] + a2[cols] - it), it
+    b1, b2 = boxes1[rows], boxes2[cols]
+    it = np.prod(np.minimum(b1[:, nd:], b2[:, nd:]) - np.maximum(b1[:, :nd], b2[:, :nd]), axis=1)
+    a1 = np.prod(b1[:, nd:] - b1[:, :nd], axis=1)
+    a2 = np.prod(b2[:, nd:] - b2[:, :nd], axis=1)
+    return rows, cols, it / (a1 + a2 - it), it
 
 
 def box_iou(boxes1, boxes2=None, return_intersection=False):
@@ -84,16 +87,21 @@ def box_iou(boxes1, boxes2=None, return_intersection=False):
 
 
 def rle_encode(indices):
-    """array_utils.py:209-235"""
+    """array_utils.py:209-235 (emp_rle_encode)"""
     indices = np.asarray(indices)
-    changes = np.where(indices[1:] != indices[:-1] + 1)[0] + 1
-    changes = np.concatenate([[0], changes, [len(indices)]]).astype(np.int64)
-    return indices[changes[:-1]], changes[1:] - changes[:-1]
+    if len(indices) == 0:
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")     # what the reference does
+    _hip.require_gpu()
+    st, rn = _hip.rle_encode(_dev(indices, np.int64))
+    return st.cpu().numpy().astype(indices.dtype, copy=False), rn.cpu().numpy()
 
 
 def rle_decode(starts, runs):
-    """array_utils.py:237-252"""
-    return np.concatenate([np.arange(s, s + r) for s, r in zip(starts, runs)])
+    """array_utils.py:237-252 (emp_rle_decode)"""
+    if len(starts) == 0:
+        raise ValueError("need at least one array to concatenate")
+    _hip.require_gpu()
+    return _hip.rle_decode(_dev(starts, np.int64), _dev(runs, np.int64)).cpu().numpy()
 
 
 def rle_to_string(starts, runs):
@@ -127,9 +135,6 @@ def concat_sort_ranges(list_of_ranges):
 
 
 # ----------------------------------------------------------------------------- HIP-backed
-def _dev(a, dtype):
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
-
 
 def rle_pair_intersections(starts_list, runs_list, pairs):
     """Intersections for many (a, b) pairs of instances at once (emp_rle_pair_intersections).

@@ -426,3 +426,78 @@ extern "C" int emp_scatter_yz_u32(uint32_t *vol, int Z, int Y, int X, const int3
     EMP_CHECK_LAUNCH("emp_scatter_yz_u32");
     return EMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// R3: RLE <-> index lists (array_utils.py:209-252).
+// decode: run i writes starts[i] .. starts[i]+runs[i]-1 at out[off[i] ..]; off = exclusive scan of runs (caller).
+// encode: a sorted index list is cut where idx[i] != idx[i-1] + 1; flags -> scan -> compaction (caller scans).
+__global__ __launch_bounds__(256) void rle_decode_kernel(const int64_t *__restrict__ starts,
+                                                         const int64_t *__restrict__ runs,
+                                                         const int64_t *__restrict__ off, int64_t n_runs,
+                                                         int64_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_runs; r += n_waves) {
+        const int64_t s = starts[r], o = off[r], len = runs[r];
+        for (int64_t i = lane; i < len; i += 64) out[o + i] = s + i;
+    }
+}
+
+extern "C" int emp_rle_decode(const int64_t *starts, const int64_t *runs, const int64_t *offsets, int64_t n_runs,
+                              int64_t *out_indices, void *stream)
+{
+    EMP_REQUIRE(n_runs >= 0, "rle_decode: bad size");
+    if (n_runs == 0) return EMP_OK;
+    EMP_REQUIRE(starts && runs && offsets && out_indices, "rle_decode: null pointer");
+    hipLaunchKernelGGL(rle_decode_kernel, dim3(emp_grid(n_runs * 64, 256, 8192)), dim3(256), 0, emp_stream(stream),
+                       starts, runs, offsets, n_runs, out_indices);
+    EMP_CHECK_LAUNCH("emp_rle_decode");
+    return EMP_OK;
+}
+
+__global__ void rle_encode_flags_kernel(const int64_t *__restrict__ idx, int64_t n, int32_t *__restrict__ flags)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        flags[i] = (i == 0 || idx[i] != idx[i - 1] + 1) ? 1 : 0;
+}
+
+__global__ void rle_encode_emit_kernel(const int64_t *__restrict__ idx, int64_t n, const int32_t *__restrict__ flags,
+                                       const int32_t *__restrict__ scan, int64_t *__restrict__ starts,
+                                       int64_t *__restrict__ runs)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (flags[i]) {
+            int64_t j = i + 1;                       // run ends at the next flag; runs are short on average
+            while (j < n && !flags[j]) ++j;
+            starts[scan[i]] = idx[i];
+            runs[scan[i]] = j - i;
+        }
+    }
+}
+
+extern "C" int emp_rle_encode(const int64_t *indices, int64_t n, int32_t *work, int64_t *out_starts,
+                              int64_t *out_runs, int32_t *n_runs_out, void *stream)
+{
+    EMP_REQUIRE(n >= 0 && n < (1LL << 31) && n_runs_out, "rle_encode: bad arguments");
+    hipStream_t st = emp_stream(stream);
+    if (n == 0) {
+        if (hipMemsetAsync(n_runs_out, 0, sizeof(int32_t), st) != hipSuccess) EMP_FAIL(EMP_ELAUNCH, "rle_encode: memset");
+        return EMP_OK;
+    }
+    EMP_REQUIRE(indices && work && out_starts && out_runs, "rle_encode: null pointer");
+    int32_t *flags = work, *scan = work + n, *tmp = work + 2 * n + 1;
+    int grid = emp_grid(n, 256, 4096);
+    hipLaunchKernelGGL(rle_encode_flags_kernel, dim3(grid), dim3(256), 0, st, indices, n, flags);
+    int rc = emp_exclusive_scan_i32(flags, n, scan, tmp, stream);
+    if (rc != EMP_OK) return rc;
+    hipLaunchKernelGGL(rle_encode_emit_kernel, dim3(grid), dim3(256), 0, st, indices, n, flags, scan, out_starts,
+                       out_runs);
+    if (hipMemcpyAsync(n_runs_out, scan + n, sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        EMP_FAIL(EMP_ELAUNCH, "rle_encode: copy");
+    EMP_CHECK_LAUNCH("emp_rle_encode");
+    return EMP_OK;
+}
+
+extern "C" int64_t emp_rle_encode_work_elems(int64_t n) { return 2 * n + 1 + emp_scan_tmp_elems(n > 0 ? n : 1); }

@@ -168,6 +168,18 @@ int emp_runs_overlap_next(const int32_t *r_start, const int32_t *r_len, const in
                           int H, int W, int64_t label_divisor, int32_t *out_triplets,
                           int64_t cap_triplets, int32_t *n_out, void *stream);
 
+/* ---- R3: run-length encoding of index lists ----------------------------------------------------
+ * replaces rle_encode / rle_decode                empanada/array_utils.py:209-252
+ * emp_rle_decode: offsets = exclusive prefix sum of runs (n_runs entries); out_indices receives
+ *   starts[i] .. starts[i]+runs[i]-1 at offsets[i].
+ * emp_rle_encode: indices (n, ascending) -> maximal runs of consecutive values; out_starts / out_runs hold
+ *   up to n entries, n_runs_out (device int32[1]) the count; work: emp_rle_encode_work_elems(n) int32.        */
+int emp_rle_decode(const int64_t *starts, const int64_t *runs, const int64_t *offsets, int64_t n_runs,
+                   int64_t *out_indices, void *stream);
+int64_t emp_rle_encode_work_elems(int64_t n);
+int emp_rle_encode(const int64_t *indices, int64_t n, int32_t *work, int64_t *out_starts,
+                   int64_t *out_runs, int32_t *n_runs_out, void *stream);
+
 /* ---- M1: box screening ------------------------------------------------------------------------
  * replaces _box_iou / box_iou                     empanada/array_utils.py:144-207 (which pairs exist)
  *          bounding_box_screening                  empanada/consensus.py:197-231

@@ -351,3 +351,52 @@ def test_sort(hip):
     ko, vo = hip.sort_u64_i32(torch.from_numpy(k.view(np.int64)).cuda().view(torch.uint64), torch.from_numpy(v).cuda())
     order = np.argsort(k, kind='stable')
     np.testing.assert_array_equal(vo.cpu().numpy(), v[order])
+
+
+def test_rle_encode_decode(hip):
+    """emp_rle_encode / emp_rle_decode vs the reference's golden index lists and the oracle."""
+    from empanada_amd import array_utils as AU
+    from oracle import rle_ops as OR
+    g = load_golden('array_utils')
+    for i in range(6):
+        for key in 'abc':
+            idx = g[f'u{i}_{key}']
+            s, r = AU.rle_encode(idx)
+            es, er = OR.rle_encode(idx)
+            np.testing.assert_array_equal(s, es); np.testing.assert_array_equal(r, er)
+            np.testing.assert_array_equal(AU.rle_decode(s, r), idx)
+        np.testing.assert_array_equal(AU.rle_encode(g[f'u{i}_a'])[0], g[f'u{i}_sa'])
+        np.testing.assert_array_equal(AU.rle_encode(g[f'u{i}_a'])[1], g[f'u{i}_ra'])
+    rng = np.random.default_rng(5)
+    for n, p in ((1, 1.0), (2, 0.5), (100000, 0.3), (300000, 0.97)):
+        idx = np.flatnonzero(rng.random(n) < p)
+        if len(idx) == 0:
+            idx = np.array([0])
+        s, r = AU.rle_encode(idx)
+        es, er = OR.rle_encode(idx)
+        np.testing.assert_array_equal(s, es); np.testing.assert_array_equal(r, er)
+        np.testing.assert_array_equal(AU.rle_decode(s, r), idx)
+    # one very long run and duplicate indices (each duplicate starts a new run, like the reference)
+    s, r = AU.rle_encode(np.arange(7, 7 + 200000))
+    assert s.tolist() == [7] and r.tolist() == [200000]
+    dup = np.array([3, 3, 4, 4, 5])
+    np.testing.assert_array_equal(AU.rle_encode(dup)[0], OR.rle_encode(dup)[0])
+    np.testing.assert_array_equal(AU.rle_encode(dup)[1], OR.rle_encode(dup)[1])
+    with pytest.raises(IndexError):
+        AU.rle_encode(np.zeros(0, dtype=np.int64))
+    with pytest.raises(ValueError):
+        AU.rle_decode(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+
+
+def test_box_pairs_golden(hip):
+    from empanada_amd import array_utils as AU
+    g = load_golden('array_utils')
+    for nd in (2, 3):
+        a, b = g[f'box{nd}_a'], g[f'box{nd}_b']
+        r, c, iou, inter = AU.box_pairs(a, b)
+        assert np.all(np.diff(r * len(b) + c) > 0)                      # row-major, unique
+        dense_iou = np.zeros((len(a), len(b))); dense_iou[r, c] = iou
+        dense_int = np.zeros((len(a), len(b))); dense_int[r, c] = inter
+        np.testing.assert_array_equal(dense_iou, g[f'box{nd}_iou'])
+        np.testing.assert_array_equal(dense_int, g[f'box{nd}_inter'])
+        np.testing.assert_array_equal(AU.box_iou(a, b).toarray(), g[f"box{nd}_iou"])

@@ -44,3 +44,21 @@ def test_config_base_inheritance(tmp_path):
     from empanada_amd import models
     m = models.__dict__[cfg['MODEL']['arch']](**{k: v for k, v in cfg['MODEL'].items() if k != 'arch'})
     assert sum(p.numel() for p in m.parameters()) > 1e6
+
+
+def test_detection_metric_kats():
+    """instance_metrics.py / panoptic_metrics.py on hand-computed cases (CPU only: no library call)."""
+    import numpy as np
+    from empanada_amd import evaluation as EV
+    kw = dict(gt_matched=np.array([1, 2, 3]), pred_matched=np.array([4, 5, 6]), gt_unmatched=np.array([7]),
+              pred_unmatched=np.array([8, 9]), matched_ious=np.array([0.9, 0.6, 0.4]))
+    # tp 2, failed 1 -> fp 3, fn 2
+    assert EV.f1_50(**kw) == 2 / (2 + 1.5 + 1.0) and EV.ap(**kw) == 2 / 7
+    assert EV.precision_50(**kw) == 2 / 5 and EV.recall_50(**kw) == 2 / 4
+    assert EV.f1_75(**kw) == 1 / (1 + 2.0 + 1.5) and EV.precision_75(**kw) == 1 / 5 and EV.recall_75(**kw) == 1 / 4
+    assert abs(EV.panoptic_quality(**kw) - (1.5 / (2 + 1e-5)) * (2 / 4.5)) < 1e-15
+    e = np.array([])
+    empty = dict(gt_matched=e, pred_matched=e, gt_unmatched=e, pred_unmatched=e, matched_ious=e)
+    assert EV.f1_50(**empty) == 1 and EV.ap(**empty) == 1 and EV.precision_50(**empty) == 1
+    assert EV.recall_50(**empty) == 1 and EV.panoptic_quality(**empty) == 1
+    assert EV.iou(np.zeros((0, 2)), np.zeros((0, 2))) == 1 and EV.iou(np.zeros((0, 2)), np.array([[1, 2]])) == 0

@@ -338,3 +338,41 @@ def test_partial_trackers_stitch_equals_whole_axis():
         solo = sharded.sharded_track_plane(pan, name, shape, 0, labels, thing, 1000)
         for a, b in zip(solo, whole):
             assert_instances_equal(a.instances, b.instances)
+
+
+def test_evaluator_on_tracker_jsons(tmp_path):
+    """Evaluator over two tracker json files (evaluator.py:24-122): the RLE route (rle_matcher on run tables)
+    and the voxel route (volume_pq: joint histogram of the filled volumes) must agree on PQ; F1/precision/recall
+    follow from the same match."""
+    from empanada_amd import evaluation as EV
+    from empanada_amd.inference import patterns as PA
+    shape = (20, 64, 72)
+    lab_gt, _ = SY.planted_labels(shape, fill=0.2, rmin=4, rmax=10, seed=3)
+    lab_pr = lab_gt.copy()
+    ids = np.unique(lab_gt)[1:]
+    lab_pr[lab_pr == ids[0]] = 0                                      # one miss
+    lab_pr[:, :, 36:][lab_pr[:, :, 36:] == ids[1]] = 0                # one shrunk object
+    lab_pr[0:2, 0:2, 0:2] = lab_gt.max() + 5                          # one false positive
+    paths = []
+    for name, lab in (('gt', lab_gt), ('pred', lab_pr)):
+        pan = torch.from_numpy(np.where(lab > 0, 1000 + lab, 0).astype(np.int32)).cuda()
+        tr = PA.track_stack(pan, 'xy', shape, [1], [1], 1000, 0.25, 0.25)[0]
+        p = str(tmp_path / f'{name}.json')
+        tr.write_to_json(p)
+        paths.append(p)
+    ev = EV.Evaluator(semantic_metrics={'iou': EV.iou},
+                      instance_metrics={'f1_50': EV.f1_50, 'f1_75': EV.f1_75, 'precision_50': EV.precision_50,
+                                        'recall_50': EV.recall_50, 'ap': EV.ap},
+                      panoptic_metrics={'pq': EV.panoptic_quality})
+    res, inst = ev(paths[0], paths[1], return_instances=True)
+    pq_vox, n_gt, n_pr, n_match = EV.volume_pq(lab_gt, lab_pr)
+    assert len(inst['gt_matched']) == n_match and len(inst['gt_unmatched']) == n_gt - n_match
+    assert abs(res['pq'] - pq_vox) < 1e-12
+    tp = int(np.count_nonzero(inst['matched_ious'] >= 0.5))
+    fp = len(inst['pred_unmatched']); fn = len(inst['gt_unmatched'])
+    assert res['f1_50'] == tp / (tp + 0.5 * fp + 0.5 * fn) and res['ap'] == tp / (tp + fp + fn)
+    assert res['precision_50'] == tp / (tp + fp) and res['recall_50'] == tp / (tp + fn)
+    assert res['f1_75'] <= res['f1_50'] < 1
+    inter = np.count_nonzero((lab_gt > 0) & (lab_pr > 0)); union = np.count_nonzero((lab_gt > 0) | (lab_pr > 0))
+    assert res['iou'] == inter / union
+    assert ev(paths[0], paths[0])['pq'] == pytest.approx(1.0, abs=1e-4)
