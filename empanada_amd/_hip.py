@@ -34,6 +34,7 @@ SIGNATURES = {
     'emp_last_error': (_c.c_char_p, []),
     'emp_device_count': (_I, []),
     'emp_bn_act_nhwc': (_I, [_P, _P, _P, _P, _I, _L, _I, _P, _P]),
+    'emp_dwconv_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
@@ -428,3 +429,14 @@ def rle_encode(indices):
     call('emp_rle_encode', _ptr(indices.contiguous()), n, _ptr(work), _ptr(st), _ptr(rn), _ptr(cnt), stream())
     k = int(cnt.item())
     return st[:k], rn[:k]
+
+
+def dwconv_nhwc(x, w_kkc, bias, k):
+    """x: (N, C, H, W) fp32 tensor in channels_last memory; w_kkc: (k*k, C); returns a new channels_last tensor
+    (emp_dwconv_nhwc)."""
+    require_gpu()
+    N, C, H, W = x.shape
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    call('emp_dwconv_nhwc', x.data_ptr(), _ptr(w_kkc), _ptr(bias), N, H, W, C, k, y.data_ptr(), stream())
+    return y

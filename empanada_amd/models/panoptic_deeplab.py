@@ -59,6 +59,33 @@ def _bn_affine(bn):
     return scale, shift
 
 
+class DepthwiseConvNHWC(nn.Module):
+    """Inference-only stand-in for Conv2d(C, C, k, padding=k//2, groups=C) on NHWC fp32 activations:
+    emp_dwconv_nhwc (one HBM pass) instead of MIOpen's grouped-convolution kernel."""
+
+    def __init__(self, conv):
+        super().__init__()
+        k = conv.kernel_size[0]
+        C = conv.in_channels
+        # (C, 1, k, k) -> (k*k, C)
+        self.register_buffer('w_kkc', conv.weight.detach().float().reshape(C, k * k).t().contiguous())
+        self.register_buffer('b', conv.bias.detach().float().contiguous() if conv.bias is not None else None)
+        self.k = k
+
+    @staticmethod
+    def eligible(m):
+        return (isinstance(m, nn.Conv2d) and m.groups == m.in_channels == m.out_channels and m.in_channels % 4 == 0
+                and m.kernel_size[0] == m.kernel_size[1] and m.kernel_size[0] in (3, 5) and m.stride == (1, 1)
+                and m.dilation == (1, 1) and m.padding == (m.kernel_size[0] // 2,) * 2
+                and m.padding_mode == 'zeros')
+
+    def forward(self, x):
+        from .. import _hip
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        return _hip.dwconv_nhwc(x, self.w_kkc, self.b, self.k)
+
+
 class FusedBNAct(nn.Module):
     """Inference-only stand-in for BatchNorm2d(+ReLU): one in-place HIP pass (emp_bn_act_nhwc) over the NHWC
     conv output instead of separate MIOpen batch-norm and ReLU kernels."""
@@ -429,9 +456,21 @@ def fuse_bn_act(model):
     return model
 
 
+def swap_depthwise(model):
+    """Swap every stride-1 depthwise Conv2d (3x3 / 5x5, zero "same" padding) for DepthwiseConvNHWC."""
+    for m in model.modules():
+        for name, child in list(m.named_children()):
+            if DepthwiseConvNHWC.eligible(child):
+                if isinstance(m, nn.Sequential):
+                    m[int(name)] = DepthwiseConvNHWC(child)
+                else:
+                    setattr(m, name, DepthwiseConvNHWC(child))
+    return model
+
+
 def prepare_for_inference(model, device='cuda', dtype=torch.float32, channels_last=True, fuse=True):
     """eval(), move to the GPU, NHWC memory format (MIOpen's fast layout on gfx950), optional bf16/fp16
-    weights, and (fp32 NHWC only) the fused BatchNorm+ReLU(+residual) epilogue kernel.  fp32 is the default so
+    weights, and (fp32 NHWC only) the fused BatchNorm+ReLU(+residual) epilogue and depthwise-convolution kernels.  fp32 is the default so
     that logits stay within the stated tolerance of the CPU reference."""
     model = model.eval().to(device)
     if channels_last:
@@ -439,5 +478,5 @@ def prepare_for_inference(model, device='cuda', dtype=torch.float32, channels_la
     if dtype != torch.float32:
         model = model.to(dtype)
     elif fuse and channels_last and torch.device(device).type == 'cuda':
-        model = fuse_bn_act(model)
+        model = swap_depthwise(fuse_bn_act(model))
     return model

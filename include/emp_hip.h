@@ -52,6 +52,17 @@ int emp_device_count(void);
 int emp_bn_act_nhwc(const float *x, const float *scale, const float *shift, const float *residual,
                     int relu, int64_t n_pixels, int C, float *out, void *stream);
 
+/* ---- D2: depthwise k x k convolution on NHWC fp32 activations (stride 1, zero "same" padding) -------
+ * replaces the depthwise half of SeparableConv2d   empanada/models/blocks.py:15-33
+ *          (decoder fuse stages                     empanada/models/decoders/panoptic_deeplab.py:52-60,
+ *           head trunks                             empanada/models/heads.py:9-19)
+ * y[n, r, c, ch] = bias[ch] + sum_{i, j} x[n, r + i - k/2, c + j - k/2, ch] * w_kkc[(i * k + j) * C + ch]
+ * evaluated as one fp32 FMA chain over the taps in raster order (i, then j) starting from +0; taps outside the
+ * image contribute fma(0, w, acc).  x, y: (N, H, W, C) fp32; w_kkc: (k*k, C) (the (C, 1, k, k) Conv2d weight
+ * transposed); bias: (C) or NULL; k in {3, 5}; C % 4 == 0; all pointers 16-byte aligned; y must not alias x. */
+int emp_dwconv_nhwc(const float *x, const float *w_kkc, const float *bias, int N, int H, int W, int C,
+                    int k, float *y, void *stream);
+
 /* ---- P1 + P2: recursive median over a resident stack, fused with hardening ----------------
  * replaces _MedianQueue.get_next/get_median/end   empanada/inference/engines.py:47-90
  *          _harden_seg / harden_seg               engines.py:114-121, inference/patterns.py:242-251

@@ -42,5 +42,7 @@ def lib():
         L.emp_oracle_fill_u32.restype = None
         L.emp_oracle_fill_u32.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int64, i64p,
                                           i64p, ctypes.c_int64, ctypes.c_uint32]
+        L.emp_oracle_dwconv_nhwc.restype = None
+        L.emp_oracle_dwconv_nhwc.argtypes = [f32p, f32p, f32p] + [ctypes.c_int] * 5 + [f32p]
         _lib = L
     return _lib

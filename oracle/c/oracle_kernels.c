@@ -187,3 +187,30 @@ void emp_oracle_fill_u32(uint32_t *vol, int64_t nvox, const int64_t *starts,
         for (int64_t j = s; j < e; ++j) vol[j] = value;
     }
 }
+
+/* Depthwise k x k convolution, NHWC fp32, stride 1, zero "same" padding: the depthwise half of
+ * SeparableConv2d (empanada/models/blocks.py:15-33; torch Conv2d with groups == channels).
+ * The reference leaves the summation order to the backend; this restatement fixes it to the order the
+ * HIP kernel documents (include/emp_hip.h, D2): one fmaf chain over the taps in raster order from +0,
+ * out-of-image taps entering as 0, bias (or +0) added last.  Agreement with torch's own conv2d is a
+ * tolerance test (tests/test_hip_kernels.py). */
+void emp_oracle_dwconv_nhwc(const float *x, const float *w_kkc, const float *bias, int N, int H, int W,
+                            int C, int k, float *y)
+{
+    const int P = k / 2;
+    for (int n = 0; n < N; ++n)
+        for (int r = 0; r < H; ++r)
+            for (int c = 0; c < W; ++c)
+                for (int ch = 0; ch < C; ++ch) {
+                    float acc = 0.0f;
+                    for (int i = 0; i < k; ++i)
+                        for (int j = 0; j < k; ++j) {
+                            int rr = r + i - P, cc = c + j - P;
+                            float v = 0.0f;
+                            if (rr >= 0 && rr < H && cc >= 0 && cc < W)
+                                v = x[(((int64_t)n * H + rr) * W + cc) * C + ch];
+                            acc = fmaf(v, w_kkc[(int64_t)(i * k + j) * C + ch], acc);
+                        }
+                    y[(((int64_t)n * H + r) * W + c) * C + ch] = acc + (bias ? bias[ch] : 0.0f);
+                }
+}

@@ -400,3 +400,36 @@ def test_box_pairs_golden(hip):
         np.testing.assert_array_equal(dense_iou, g[f'box{nd}_iou'])
         np.testing.assert_array_equal(dense_int, g[f'box{nd}_inter'])
         np.testing.assert_array_equal(AU.box_iou(a, b).toarray(), g[f"box{nd}_iou"])
+
+
+@pytest.mark.parametrize('k,shape,bias', [(5, (2, 37, 29, 32), False), (3, (1, 8, 6, 8), True),
+                                          (5, (3, 64, 64, 72), True), (5, (1, 2, 3, 4), False),
+                                          (3, (2, 70, 33, 260), False)])
+def test_dwconv_nhwc(hip, k, shape, bias):
+    """emp_dwconv_nhwc: bit-exact against the C oracle (same fma chain), and within fp32 rounding of torch's
+    conv2d(groups=C), the call the reference makes (blocks.py:27).  Tolerance: |err| <= 1e-5 * (sum |x||w| + 1)."""
+    from oracle import dense as OD
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(k * 1000 + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.2
+    b = torch.randn(C, generator=g) if bias else None
+    w_kkc = w.reshape(C, k * k).t().contiguous()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    got = hip.dwconv_nhwc(xd, w_kkc.cuda(), b.cuda() if bias else None, k)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    got_nhwc = got.permute(0, 2, 3, 1).cpu().numpy()
+    exp = OD.dwconv_nhwc(x.permute(0, 2, 3, 1).numpy(), w_kkc.numpy(), b.numpy() if bias else None)
+    np.testing.assert_array_equal(got_nhwc.view(np.uint32), exp.view(np.uint32))
+    ref = torch.nn.functional.conv2d(x, w, b, padding=k // 2, groups=C)
+    bound = torch.nn.functional.conv2d(x.abs(), w.abs(), None, padding=k // 2, groups=C) + 1
+    assert torch.all((got.cpu() - ref).abs() <= 1e-5 * bound)
+
+
+def test_dwconv_argument_errors(hip):
+    x = torch.zeros(1, 6, 4, 4, device='cuda').contiguous(memory_format=torch.channels_last)
+    with pytest.raises(hip.HipError):
+        hip.dwconv_nhwc(x, torch.zeros(25, 6, device='cuda'), None, 5)        # C % 4 != 0
+    x = torch.zeros(1, 8, 4, 4, device='cuda').contiguous(memory_format=torch.channels_last)
+    with pytest.raises(hip.HipError):
+        hip.dwconv_nhwc(x, torch.zeros(49, 8, device='cuda'), None, 7)        # unsupported k
