@@ -50,6 +50,10 @@ PMC_TRAFFIC_BYTES_PER_VOXEL = {
     'emp_median_harden_stack': 5.02, 'emp_find_centers': 4.56, 'emp_group_pixels': 4.60, 'emp_fuse_apply': 7.01,
     'emp_runs_count': 4.02, 'emp_runs_extract': 4.15,
 }
+# same, as a ratio to the algorithmic bytes, for the dense-path kernels whose shapes vary from call to call
+# (profiles/r1_pmc_dense.md)
+PMC_TRAFFIC_RATIO = {'emp_bn_act_nhwc': None, 'emp_dwconv_nhwc': None}
+DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc')
 HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -378,35 +382,45 @@ def main():
             out = pipe.postprocess(heads, host_out)
             ev[3 * k + 2].record()
     else:
-        # Software pipeline over consecutive passes: while the GPU runs the forward of pass k, the host runs the
-        # label-propagation chain of pass k-1 (the only serial, host-side stage); its fill + D2H are queued behind
-        # the forward.  All K passes complete inside the timed region (drain below).
-        pending = None
+        # Software pipeline over consecutive passes on two HIP streams.  The forward of pass k is queued on the
+        # default stream first; everything downstream of pass k-1's forward (pixel kernels, run tables and their
+        # D2H, the host label-propagation chain, fill, D2H of the labelled slab) then runs on the post-processing
+        # stream behind an event of forward k-1, concurrently with forward k.  The host never blocks the forward
+        # queue, and all K passes complete inside the timed region (drain iteration + barrier below).
+        post = pipe.post_stream
+        fwd_done = [torch.cuda.Event() for _ in range(args.steps)]
+
+        def downstream(k):
+            with torch.cuda.stream(post):
+                post.wait_event(fwd_done[k])
+                pan = sharded.sharded_panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'],
+                                                     coarse_boundaries=False, **ENGINE)
+                table, host = sharded.sharded_tables(pan, [1], ENGINE['thing_list'], ENGINE['label_divisor'])
+                tc = time.perf_counter()
+                final = sharded.gather_tables_and_chain(host, pan.shape[0], [1], ENGINE['thing_list'],
+                                                        ENGINE['label_divisor'], min_size=FILTERS['min_size'],
+                                                        min_span=FILTERS['min_span'], **MATCH)
+                pipe.timers.setdefault('chain_s', []).append(time.perf_counter() - tc)
+                out = sharded.fill_slab(table, final, tuple(pan.shape))
+                host_out.copy_(out.view(torch.int32), non_blocking=True)
+                ev[3 * k + 2].record()
+            return out
+
         for k in range(args.steps + 1):
             if k < args.steps:
                 ev[3 * k].record()
                 prob, chk = pipe.forward(vol)                      # asynchronous: only enqueues
                 ev[3 * k + 1].record()
-            if pending is not None:
-                table, host, shape_l = pending
-                tc = time.perf_counter()
-                final = sharded.gather_tables_and_chain(host, shape_l[0], [1], ENGINE['thing_list'],
-                                                        ENGINE['label_divisor'], min_size=FILTERS['min_size'],
-                                                        min_span=FILTERS['min_span'], **MATCH)
-                pipe.timers.setdefault('chain_s', []).append(time.perf_counter() - tc)
-                out = sharded.fill_slab(table, final, shape_l)
-                host_out.copy_(out.view(torch.int32), non_blocking=True)
-                pending = None
-            if k < args.steps:
-                pan = sharded.sharded_panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'],
-                                                     coarse_boundaries=False, **ENGINE)
-                table, host = sharded.sharded_tables(pan, [1], ENGINE['thing_list'], ENGINE['label_divisor'])
-                ev[3 * k + 2].record()
-                pending = (table, host, tuple(pan.shape))
+                fwd_done[k].record()
+                _hip.PROFILE_SKIP.update(DENSE_KERNELS)            # the dense-path calls are sampled in pass 0
+            if k > 0:
+                out = downstream(k - 1)
+        torch.cuda.current_stream().wait_stream(post)
     barrier()
     dt = time.perf_counter() - t0
     log(f'timed {args.steps} steps in {dt:.2f}s')
     prof, _hip.PROFILE = _hip.PROFILE, None
+    _hip.PROFILE_SKIP.clear()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -417,16 +431,36 @@ def main():
         ms_step = dt / args.steps * 1e3
         fwd_ms = np.mean([ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(args.steps)])
         post_ms = np.mean([ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(args.steps)])
-        kern = {name: float(np.mean([a.elapsed_time(b) for a, b in evs])) for name, evs in prof.items()}
-        per_call = {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}
-        # dominant hand-written kernel among the per-voxel, single-kernel ABI calls
         thing_frac = float((heads['sem'] >= ENGINE['confidence_thr']).float().mean().item())
-        dom = max((k for k in kern if k in ALG_BYTES), key=lambda k: kern[k])
-        alg_bpv = ALG_BYTES[dom](thing_frac)
-        alg = alg_bpv * float(D) * S * S
-        ach = alg / (kern[dom] * 1e-3) / 1e9
-        roofs = {k: round(ALG_BYTES[k](thing_frac) * float(D) * S * S / (kern[k] * 1e-3) / 1e9, 1)
-                 for k in kern if k in ALG_BYTES}
+        vox = float(D) * S * S
+        # per ABI call: launches, total ms and algorithmic bytes inside the timed region.  The per-voxel kernels
+        # process the whole slab in one launch (ALG_BYTES x voxels); the dense-path kernels report their bytes
+        # per call (shapes vary by layer) and are sampled during the first timed pass.
+        stat = {}
+        for name, evs in prof.items():
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            by = [nb if nb is not None else (ALG_BYTES[name](thing_frac) * vox if name in ALG_BYTES else None)
+                  for _, _, nb in evs]
+            passes = 1 if (name in DENSE_KERNELS and not args.no_pipeline) else args.steps
+            stat[name] = {'calls_per_pass': len(ms) / passes, 'ms_per_pass': float(np.sum(ms)) / passes,
+                          'avg_ms': float(np.mean(ms)),
+                          'bytes': float(np.sum(by)) if all(b is not None for b in by) else None}
+        kern = {k: v['avg_ms'] for k, v in stat.items()}
+        per_call = {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}
+        per_pass = {k: round(v['ms_per_pass'], 3) for k, v in sorted(stat.items(), key=lambda kv: -kv[1]['ms_per_pass'])}
+        roofs = {k: round(v['bytes'] / (v['avg_ms'] * len(prof[k]) * 1e-3) / 1e9, 1)
+                 for k, v in stat.items() if v['bytes'] is not None}
+        # dominant hand-written kernel = most GPU time per pass among the calls with a byte model
+        dom = max((k for k in stat if stat[k]['bytes'] is not None), key=lambda k: stat[k]['ms_per_pass'])
+        n_dom = len(prof[dom])
+        alg = stat[dom]['bytes'] / n_dom                                  # algorithmic bytes per launch (mean)
+        ach = roofs[dom]
+        if dom in PMC_TRAFFIC_BYTES_PER_VOXEL:
+            traffic = round(PMC_TRAFFIC_BYTES_PER_VOXEL[dom] * vox)
+        elif PMC_TRAFFIC_RATIO.get(dom) is not None:
+            traffic = round(PMC_TRAFFIC_RATIO[dom] * alg)
+        else:
+            traffic = None
         flops = 414477.0 * D * S * S                                      # PDL-R50, C=1
         res = {
             'metric': 'Mvox/s end-to-end 3D panoptic inference (incl. consensus); PQ vs CPU ref',
@@ -438,16 +472,19 @@ def main():
                                    f'(ks=7, full-res heads), {n_obj} planted objects per rank',
                        'mode': 'stack', 'slices_per_rank': D, 'batch': args.batch,
                        'objects_found': int(len(np.unique(host_out.numpy())) - 1)},
-            'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'postprocess_to_host': round(float(post_ms), 2),
+            'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'forward_end_to_slab_on_host': round(float(post_ms), 2),
                              'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2),
                              'pipelined': not args.no_pipeline,
                              'host_chain_s': round(float(np.mean(pipe.timers.get('chain_s', [0]))), 4)},
             'hip_calls_ms': per_call,
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                         'traffic': round(PMC_TRAFFIC_BYTES_PER_VOXEL[dom] * float(D) * S * S),
-                         'alg_bytes_per_launch': round(alg), 'alg_bytes_per_voxel': round(alg_bpv, 3),
-                         'avg_launch_ms': round(kern[dom], 4), 'thing_fraction': round(thing_frac, 4),
+            'hip_ms_per_pass': per_pass,
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'alg_bytes_per_launch': round(alg), 'avg_launch_ms': round(kern[dom], 4),
+                         'launches_per_pass': stat[dom]['calls_per_pass'],
+                         'ms_per_pass': round(stat[dom]['ms_per_pass'], 3),
+                         'thing_fraction': round(thing_frac, 4),
+                         'alg_bytes_per_voxel': {k: round(f(thing_frac), 3) for k, f in ALG_BYTES.items()},
                          'all_kernels_GBps': roofs},
         }
         if not args.no_cpu_baseline and world == 1:

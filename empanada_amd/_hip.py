@@ -33,8 +33,9 @@ SIGNATURES = {
     'emp_version': (_I, []),
     'emp_last_error': (_c.c_char_p, []),
     'emp_device_count': (_I, []),
-    'emp_bn_act_nhwc': (_I, [_P, _P, _P, _P, _I, _L, _I, _P, _P]),
+    'emp_bn_act_nhwc': (_I, [_P, _P, _P, _P, _I, _L, _I, _P, _L, _P]),
     'emp_dwconv_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    'emp_upsample_bilinear': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
@@ -117,21 +118,24 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# optional per-call HIP-event timing (bench.py): name -> list of (start_event, end_event).  Events are recorded
-# on the stream the kernels are launched on (torch's current stream) and only read after the final sync.
+# optional per-call HIP-event timing (bench.py): name -> list of (start_event, end_event, algorithmic bytes or
+# None).  Events are recorded on the stream the kernels are launched on (torch's current stream) and only read
+# after the final sync.  Names in PROFILE_SKIP are not timed (bench.py samples the ~1600 dense-path calls of a
+# pass in one pass only, so that event packets do not perturb the others).
 PROFILE = None
+PROFILE_SKIP = set()
 
 
-def call(name, *args):
+def call(name, *args, alg_bytes=None):
     """Call an int-returning ABI function; raise HipError with emp_last_error() on failure."""
     lib = load()
-    if PROFILE is not None:
+    if PROFILE is not None and name not in PROFILE_SKIP:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(lib, name)(*args)
         e1.record()
-        PROFILE.setdefault(name, []).append((e0, e1))
+        PROFILE.setdefault(name, []).append((e0, e1, alg_bytes))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:
@@ -363,15 +367,24 @@ def fill_table_u32(vol, table, value_u32, slice0=0):
     return vol
 
 
-def bn_act_nhwc_(x, scale, shift, residual=None, relu=True):
-    """in place on x (N,C,H,W fp32 in channels_last memory): relu?(x*scale[c] + shift[c] (+ residual))."""
+def bn_act_nhwc_(x, scale, shift, residual=None, relu=True, out=None):
+    """relu?(x*scale[c] + shift[c] (+ residual)) on x (N,C,H,W fp32 in channels_last memory); in place on x, or
+    written to `out`: an (N,C,H,W) channel slice of a wider channels_last buffer."""
     N, C, H, W = x.shape
     assert x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32
     if residual is not None:
         assert residual.shape == x.shape and residual.is_contiguous(memory_format=torch.channels_last)
+    ostride = 0
+    dst = x
+    if out is not None:
+        assert out.shape == x.shape and out.dtype == torch.float32 and out.stride(1) == 1
+        ostride = out.stride(3)
+        assert out.stride(2) == W * ostride and out.stride(0) == H * W * ostride, "out must be an NHWC channel slice"
+        dst = out
     call('emp_bn_act_nhwc', x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-         residual.data_ptr() if residual is not None else None, int(bool(relu)), N * H * W, C, x.data_ptr(), stream())
-    return x
+         residual.data_ptr() if residual is not None else None, int(bool(relu)), N * H * W, C, dst.data_ptr(),
+         ostride, stream(), alg_bytes=4 * x.numel() * (3 if residual is not None else 2))
+    return dst
 
 
 def yz_runs_along_x(table, value_u32, shape3d, slice0=0):
@@ -438,5 +451,27 @@ def dwconv_nhwc(x, w_kkc, bias, k):
     N, C, H, W = x.shape
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
     y = torch.empty_like(x, memory_format=torch.channels_last)
-    call('emp_dwconv_nhwc', x.data_ptr(), _ptr(w_kkc), _ptr(bias), N, H, W, C, k, y.data_ptr(), stream())
+    call('emp_dwconv_nhwc', x.data_ptr(), _ptr(w_kkc), _ptr(bias), N, H, W, C, k, y.data_ptr(), stream(),
+         alg_bytes=8 * x.numel())
     return y
+
+
+def upsample_bilinear(x, size, out=None):
+    """bilinear, align_corners=True: x (N,C,h,w) fp32 cuda, any strides -> (N,C,H,W).  `out` may be any
+    (N,C,H,W) view (e.g. a channel slice of a channels_last buffer); default: same memory format as x
+    (emp_upsample_bilinear)."""
+    require_gpu()
+    import ctypes
+    N, C, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    assert x.is_cuda and x.dtype == torch.float32
+    if out is None:
+        cl = C % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last)   # few channels: planar output
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device,
+                          memory_format=torch.channels_last if cl else torch.contiguous_format)
+    assert out.shape == (N, C, H, W) and out.dtype == torch.float32 and out.is_cuda
+    xs = (ctypes.c_int64 * 4)(*x.stride())
+    ys = (ctypes.c_int64 * 4)(*out.stride())
+    call('emp_upsample_bilinear', x.data_ptr(), N, C, h, w, xs, out.data_ptr(), H, W, ys, stream(),
+         alg_bytes=4 * (x.numel() + N * C * H * W))
+    return out

@@ -129,3 +129,130 @@ extern "C" int emp_dwconv_nhwc(const float *x, const float *w_kkc, const float *
     EMP_CHECK_LAUNCH("emp_dwconv_nhwc");
     return EMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// D3: bilinear up-sampling, align_corners = True (the decoder's F.interpolate calls and the x4 up-sampling of the
+// heads).  Source coordinate = dst * (in - 1) / (out - 1) in fp32; value =
+//   (1-ly) * ((1-lx) * v00 + lx * v01) + ly * ((1-lx) * v10 + lx * v11), unfused fp32.
+// Generic element strides on both sides: the destination may be a channel slice of a wider NHWC buffer (which
+// is how the decoder's torch.cat disappears), the source may be NCHW or NHWC.
+struct UpGeom {
+    int N, C, h, w, H, W;
+    int64_t xs_n, xs_c, xs_h, xs_w, ys_n, ys_c, ys_h, ys_w;
+    float ry, rx;
+};
+
+__device__ __forceinline__ void up_src(float r, int dst, int in, int &i0, int &i1, float &l1)
+{
+    const float s = __fmul_rn(r, (float)dst);
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = __fsub_rn(s, (float)i0);
+}
+
+__device__ __forceinline__ float up_mix(float v00, float v01, float v10, float v11, float lx, float ly)
+{
+    const float lx0 = __fsub_rn(1.0f, lx), ly0 = __fsub_rn(1.0f, ly);
+    const float top = __fadd_rn(__fmul_rn(lx0, v00), __fmul_rn(lx, v01));
+    const float bot = __fadd_rn(__fmul_rn(lx0, v10), __fmul_rn(lx, v11));
+    return __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly, bot));
+}
+
+// channels innermost on both sides (xs_c == ys_c == 1, C % 4 == 0): one float4 of channels per thread
+__global__ __launch_bounds__(256) void upsample_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y, UpGeom g)
+{
+    const int C4 = g.C >> 2;
+    const int64_t total = (int64_t)g.N * g.H * g.W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int X = (int)(p % g.W);
+        p /= g.W;
+        const int Y = (int)(p % g.H);
+        const int n = (int)(p / g.H);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        up_src(g.ry, Y, g.h, y0, y1, ly);
+        up_src(g.rx, X, g.w, x0, x1, lx);
+        const float *b = x + n * g.xs_n + 4 * c4;
+        const float4 v00 = *reinterpret_cast<const float4 *>(b + y0 * g.xs_h + x0 * g.xs_w);
+        const float4 v01 = *reinterpret_cast<const float4 *>(b + y0 * g.xs_h + x1 * g.xs_w);
+        const float4 v10 = *reinterpret_cast<const float4 *>(b + y1 * g.xs_h + x0 * g.xs_w);
+        const float4 v11 = *reinterpret_cast<const float4 *>(b + y1 * g.xs_h + x1 * g.xs_w);
+        float4 o;
+        o.x = up_mix(v00.x, v01.x, v10.x, v11.x, lx, ly);
+        o.y = up_mix(v00.y, v01.y, v10.y, v11.y, lx, ly);
+        o.z = up_mix(v00.z, v01.z, v10.z, v11.z, lx, ly);
+        o.w = up_mix(v00.w, v01.w, v10.w, v11.w, lx, ly);
+        *reinterpret_cast<float4 *>(y + n * g.ys_n + Y * g.ys_h + X * g.ys_w + 4 * c4) = o;
+    }
+}
+
+// any strides: one thread per 4 consecutive output columns of one (n, c, Y) row
+__global__ __launch_bounds__(256) void upsample_planar_kernel(const float *__restrict__ x, float *__restrict__ y, UpGeom g)
+{
+    const int W4 = (g.W + 3) >> 2;
+    const int64_t total = (int64_t)g.N * g.C * g.H * W4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int X0 = (int)(i % W4) * 4;
+        int64_t p = i / W4;
+        const int Y = (int)(p % g.H);
+        p /= g.H;
+        const int c = (int)(p % g.C);
+        const int n = (int)(p / g.C);
+        int y0, y1;
+        float ly;
+        up_src(g.ry, Y, g.h, y0, y1, ly);
+        const float *r0 = x + n * g.xs_n + c * g.xs_c + y0 * g.xs_h;
+        const float *r1 = x + n * g.xs_n + c * g.xs_c + y1 * g.xs_h;
+        float *out = y + n * g.ys_n + c * g.ys_c + Y * g.ys_h;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int X = X0 + j;
+            o[j] = 0.f;
+            if (X < g.W) {
+                int x0, x1;
+                float lx;
+                up_src(g.rx, X, g.w, x0, x1, lx);
+                o[j] = up_mix(r0[x0 * g.xs_w], r0[x1 * g.xs_w], r1[x0 * g.xs_w], r1[x1 * g.xs_w], lx, ly);
+            }
+        }
+        if (g.ys_w == 1 && X0 + 3 < g.W && ((reinterpret_cast<uintptr_t>(out + X0) & 15) == 0)) {
+            *reinterpret_cast<float4 *>(out + X0) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (X0 + j < g.W) out[(X0 + j) * g.ys_w] = o[j];
+        }
+    }
+}
+
+extern "C" int emp_upsample_bilinear(const float *x, int N, int C, int h, int w, const int64_t *x_strides,
+                                     float *y, int H, int W, const int64_t *y_strides, void *stream)
+{
+    EMP_REQUIRE(x && y && x_strides && y_strides, "upsample: null pointer");
+    EMP_REQUIRE(N >= 0 && C > 0 && h > 0 && w > 0 && H > 0 && W > 0, "upsample: bad shape");
+    EMP_REQUIRE(h < (1 << 24) && w < (1 << 24) && H < (1 << 24) && W < (1 << 24), "upsample: sizes exceed fp32 integers");
+    if (N == 0) return EMP_OK;
+    UpGeom g;
+    g.N = N; g.C = C; g.h = h; g.w = w; g.H = H; g.W = W;
+    g.xs_n = x_strides[0]; g.xs_c = x_strides[1]; g.xs_h = x_strides[2]; g.xs_w = x_strides[3];
+    g.ys_n = y_strides[0]; g.ys_c = y_strides[1]; g.ys_h = y_strides[2]; g.ys_w = y_strides[3];
+    g.ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    g.rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    hipStream_t st = emp_stream(stream);
+    const bool vec = g.xs_c == 1 && g.ys_c == 1 && C % 4 == 0 &&
+                     ((g.xs_n | g.xs_h | g.xs_w | g.ys_n | g.ys_h | g.ys_w) & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (vec) {
+        const int64_t total = (int64_t)N * H * W * (C / 4);
+        hipLaunchKernelGGL(upsample_nhwc_kernel, dim3(emp_grid(total, 256, 16384)), dim3(256), 0, st, x, y, g);
+    } else {
+        const int64_t total = (int64_t)N * C * H * ((W + 3) / 4);
+        hipLaunchKernelGGL(upsample_planar_kernel, dim3(emp_grid(total, 256, 16384)), dim3(256), 0, st, x, y, g);
+    }
+    EMP_CHECK_LAUNCH("emp_upsample_bilinear");
+    return EMP_OK;
+}

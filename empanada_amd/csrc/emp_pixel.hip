@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void bn_act_nhwc_kernel(const float4 *__restri
                                                           const float4 *__restrict__ scale,
                                                           const float4 *__restrict__ shift,
                                                           const float4 *__restrict__ res, int64_t n4, int c4,
-                                                          float4 *__restrict__ out)
+                                                          int64_t out_stride4, float4 *__restrict__ out)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4);
@@ -1026,16 +1026,20 @@ __global__ __launch_bounds__(256) void bn_act_nhwc_kernel(const float4 *__restri
         if (RELU) {
             y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
         }
-        out[i] = y;
+        // out_stride4 == c4: dense output (index i); otherwise a channel slice of a wider NHWC buffer
+        out[out_stride4 == c4 ? i : (i / c4) * out_stride4 + c] = y;
     }
 }
 
 extern "C" int emp_bn_act_nhwc(const float *x, const float *scale, const float *shift, const float *residual,
-                               int relu, int64_t n_pixels, int C, float *out, void *stream)
+                               int relu, int64_t n_pixels, int C, float *out, int64_t out_pixel_stride, void *stream)
 {
     EMP_REQUIRE(x && scale && shift && out, "bn_act: null pointer");
     EMP_REQUIRE(C > 0 && C % 4 == 0, "bn_act: channel count %d must be a multiple of 4", C);
     EMP_REQUIRE(n_pixels >= 0, "bn_act: bad size");
+    if (out_pixel_stride == 0) out_pixel_stride = C;
+    EMP_REQUIRE(out_pixel_stride >= C && out_pixel_stride % 4 == 0, "bn_act: bad output pixel stride");
+    EMP_REQUIRE(out_pixel_stride == C || out != x, "bn_act: a strided output cannot alias the input");
     EMP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(scale) |
                   reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0,
                 "bn_act: pointers must be 16-byte aligned");
@@ -1046,7 +1050,7 @@ extern "C" int emp_bn_act_nhwc(const float *x, const float *scale, const float *
     const float4 *x4 = reinterpret_cast<const float4 *>(x), *s4 = reinterpret_cast<const float4 *>(scale);
     const float4 *b4 = reinterpret_cast<const float4 *>(shift), *r4 = reinterpret_cast<const float4 *>(residual);
     float4 *o4 = reinterpret_cast<float4 *>(out);
-#define EMP_BN(R, A) hipLaunchKernelGGL((bn_act_nhwc_kernel<R, A>), dim3(grid), dim3(256), 0, st, x4, s4, b4, r4, n4, C / 4, o4)
+#define EMP_BN(R, A) hipLaunchKernelGGL((bn_act_nhwc_kernel<R, A>), dim3(grid), dim3(256), 0, st, x4, s4, b4, r4, n4, C / 4, out_pixel_stride / 4, o4)
     if (residual) { if (relu) EMP_BN(true, true); else EMP_BN(true, false); }
     else { if (relu) EMP_BN(false, true); else EMP_BN(false, false); }
 #undef EMP_BN

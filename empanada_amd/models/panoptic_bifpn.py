@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .panoptic_deeplab import (PanopticDeepLabHead, PointRendSemSegHead, SeparableConv2d, _RESNETS, _conv_bn_act,
+                               _up_bilinear,
                                resnet_encoder)
 
 __all__ = ['PanopticBiFPN', 'PanopticBiFPNPR', 'regnet_encoder', 'REGNETS']
@@ -283,9 +284,10 @@ class PanopticBiFPN(nn.Module):
         self.ins_center = PanopticDeepLabHead(fpn_dim, 1)
         self.ins_xy = PanopticDeepLabHead(fpn_dim, 2)
 
-    @staticmethod
-    def _up4(x):
-        return F.interpolate(x, scale_factor=4.0, mode='bilinear', align_corners=True)
+    hip_ops = False
+
+    def _up4(self, x):
+        return _up_bilinear(x, (4 * x.shape[2], 4 * x.shape[3]), self.hip_ops)
 
     def _features(self, x):
         pyramid = self.encoder(x)

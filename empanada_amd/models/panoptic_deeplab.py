@@ -97,7 +97,7 @@ class FusedBNAct(nn.Module):
         self.register_buffer('shift', shift, persistent=False)
         self.relu = relu
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, out=None):
         from .. import _hip
         if not (x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0):
             raise RuntimeError("FusedBNAct needs fp32 CUDA activations with C % 4 == 0")
@@ -105,7 +105,33 @@ class FusedBNAct(nn.Module):
             x = x.contiguous(memory_format=torch.channels_last)
         if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
             residual = residual.contiguous(memory_format=torch.channels_last)
-        return _hip.bn_act_nhwc_(x, self.scale, self.shift, residual, self.relu)
+        return _hip.bn_act_nhwc_(x, self.scale, self.shift, residual, self.relu, out)
+
+
+def _up_bilinear(x, size, hip_ops, out=None):
+    """F.interpolate(mode='bilinear', align_corners=True), through emp_upsample_bilinear when hip_ops"""
+    if hip_ops and x.is_cuda and x.dtype == torch.float32:
+        from .. import _hip
+        return _hip.upsample_bilinear(x, size, out=out)
+    y = F.interpolate(x, size=size, mode='bilinear', align_corners=True)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def _conv_bn_into(seq, x, out):
+    """seq = Sequential(Conv2d, FusedBNAct(+ReLU), Identity...): the fused epilogue writes straight into `out`,
+    a channel slice of the caller's concat buffer"""
+    y = seq[0](x)
+    seq[1](y, out=out)
+    for extra in list(seq)[2:]:
+        assert isinstance(extra, (nn.Identity, nn.Dropout)), "unexpected module after the fused epilogue"
+
+
+def _can_write_into(seq, x):
+    return (isinstance(seq, nn.Sequential) and len(seq) >= 2 and isinstance(seq[0], nn.Conv2d)
+            and isinstance(seq[1], FusedBNAct) and x.is_cuda and x.dtype == torch.float32)
 
 
 class _Basic(nn.Module):
@@ -216,10 +242,11 @@ class _ASPPPooling(nn.Module):
     def __init__(self, nin, nout):
         super().__init__()
         self.aspp_pooling = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(nin, nout, 1, bias=False), nn.ReLU())
+        self.hip_ops = False
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         size = x.shape[-2:]
-        return F.interpolate(self.aspp_pooling(x), size=size, mode='bilinear', align_corners=True)
+        return _up_bilinear(self.aspp_pooling(x), size, self.hip_ops, out)
 
 
 class ASPP(nn.Module):
@@ -235,8 +262,22 @@ class ASPP(nn.Module):
         self.convs = nn.ModuleList(mods)
         self.project = nn.Sequential(nn.Conv2d(5 * nout, nout, 1, bias=False), nn.BatchNorm2d(nout), nn.ReLU(),
                                      nn.Dropout(dropout_p))
+        self.nout = nout
+        self.hip_ops = False
 
     def forward(self, x):
+        if self.hip_ops and all(_can_write_into(c, x) for c in list(self.convs)[:-1]):
+            # the concat buffer is allocated once and every branch's epilogue writes its own channel slice
+            n = self.nout
+            buf = torch.empty((x.shape[0], len(self.convs) * n, x.shape[2], x.shape[3]), dtype=x.dtype,
+                              device=x.device, memory_format=torch.channels_last)
+            for i, conv in enumerate(self.convs):
+                dst = buf[:, i * n:(i + 1) * n]
+                if isinstance(conv, _ASPPPooling):
+                    conv(x, out=dst)
+                else:
+                    _conv_bn_into(conv, x, dst)
+            return self.project(buf)
         return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
 
 
@@ -255,13 +296,24 @@ class PanopticDeepLabDecoder(nn.Module):
             fuse.append(_sepconv_bn_act((aspp_channels if i == 0 else decoder_channels) + pc, decoder_channels, 5))
         self.project = nn.ModuleList(project)
         self.fuse = nn.ModuleList(fuse)
+        self.hip_ops = False
 
     def forward(self, pyramid: List[torch.Tensor]):
         x = self.aspp(pyramid[-1])
         for stage, proj, fuse in zip(self.low_level_stages, self.project, self.fuse):
-            low = proj(pyramid[stage])
-            x = F.interpolate(x, size=low.shape[2:], mode='bilinear', align_corners=True)
-            x = fuse(torch.cat((x, low), dim=1))
+            feat = pyramid[stage]
+            if self.hip_ops and _can_write_into(proj, feat):
+                # up-sampled x and the projected low-level features land directly in the concat buffer
+                cx, cl = x.shape[1], proj[0].out_channels
+                buf = torch.empty((x.shape[0], cx + cl, feat.shape[2], feat.shape[3]), dtype=x.dtype,
+                                  device=x.device, memory_format=torch.channels_last)
+                _up_bilinear(x, feat.shape[2:], True, out=buf[:, :cx])
+                _conv_bn_into(proj, feat, buf[:, cx:])
+                x = fuse(buf)
+            else:
+                low = proj(feat)
+                x = _up_bilinear(x, low.shape[2:], self.hip_ops)
+                x = fuse(torch.cat((x, low), dim=1))
         return x
 
 
@@ -304,9 +356,11 @@ class PanopticDeepLab(nn.Module):
         self.ins_center = PanopticDeepLabHead(decoder_channels, 1)
         self.ins_xy = PanopticDeepLabHead(decoder_channels, 2)
 
-    @staticmethod
-    def _up4(x):
-        return F.interpolate(x, scale_factor=4.0, mode='bilinear', align_corners=True)
+    hip_ops = False
+
+    def _up4(self, x):
+        # scale_factor=4 with align_corners=True: out = 4 * in, src = dst * (in - 1) / (out - 1)
+        return _up_bilinear(x, (4 * x.shape[2], 4 * x.shape[3]), self.hip_ops)
 
     def forward(self, x):
         pyramid = self.encoder(x)
@@ -479,4 +533,7 @@ def prepare_for_inference(model, device='cuda', dtype=torch.float32, channels_la
         model = model.to(dtype)
     elif fuse and channels_last and torch.device(device).type == 'cuda':
         model = swap_depthwise(fuse_bn_act(model))
+        for m in model.modules():
+            if hasattr(m, 'hip_ops'):
+                m.hip_ops = True                  # emp_upsample_bilinear + concat buffers written in place
     return model

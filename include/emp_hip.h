@@ -48,9 +48,12 @@ int emp_device_count(void);
  *          conv_bn_act / separable_conv_bn_act     empanada/models/blocks.py:121-171
  * out[p, c] = act(x[p, c] * scale[c] + shift[c] (+ residual[p, c])), act = ReLU if relu != 0.
  * scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (precomputed by the host).
- * x, residual, out: (n_pixels, C) fp32 (NHWC memory), C % 4 == 0, 16-byte aligned; out may alias x.    */
+ * x, residual: (n_pixels, C) fp32 (NHWC memory), C % 4 == 0, 16-byte aligned.  out: pixel p starts at
+ * out + p * out_pixel_stride (floats; 0 means C): either dense (may alias x) or a channel slice of a wider NHWC
+ * buffer, which is how the torch.cat of ASPP / decoder branches (aspp.py:96-101,
+ * decoders/panoptic_deeplab.py:76-77) is written in place.                                                  */
 int emp_bn_act_nhwc(const float *x, const float *scale, const float *shift, const float *residual,
-                    int relu, int64_t n_pixels, int C, float *out, void *stream);
+                    int relu, int64_t n_pixels, int C, float *out, int64_t out_pixel_stride, void *stream);
 
 /* ---- D2: depthwise k x k convolution on NHWC fp32 activations (stride 1, zero "same" padding) -------
  * replaces the depthwise half of SeparableConv2d   empanada/models/blocks.py:15-33
@@ -62,6 +65,19 @@ int emp_bn_act_nhwc(const float *x, const float *scale, const float *shift, cons
  * transposed); bias: (C) or NULL; k in {3, 5}; C % 4 == 0; all pointers 16-byte aligned; y must not alias x. */
 int emp_dwconv_nhwc(const float *x, const float *w_kkc, const float *bias, int N, int H, int W, int C,
                     int k, float *y, void *stream);
+
+/* ---- D3: bilinear up-sampling with align_corners = True on fp32 activations ------------------------
+ * replaces F.interpolate(..., mode='bilinear', align_corners=True) in
+ *          PanopticDeepLab.forward (x4 heads)       empanada/models/panoptic_deeplab.py:100-113
+ *          PanopticDeepLabDecoder.forward           empanada/models/decoders/panoptic_deeplab.py:70-78
+ *          ASPPPooling.forward                      empanada/models/decoders/aspp.py:48-52
+ * x: logical (N, C, h, w), y: logical (N, C, H, W), both addressed through 4 element strides (n, c, h, w), so
+ * either side may be NCHW, NHWC or a channel slice of a wider NHWC buffer (the caller's torch.cat target).
+ * src = dst * (in - 1) / (out - 1) in fp32 (0 when out == 1); i0 = floor(src), l = src - i0, i1 = min(i0+1, in-1);
+ * y = (1-ly) * ((1-lx) * v00 + lx * v01) + ly * ((1-lx) * v10 + lx * v11), every operation a separate fp32
+ * rounding.  x_strides / y_strides: HOST arrays of 4 int64.                                                 */
+int emp_upsample_bilinear(const float *x, int N, int C, int h, int w, const int64_t *x_strides,
+                          float *y, int H, int W, const int64_t *y_strides, void *stream);
 
 /* ---- P1 + P2: recursive median over a resident stack, fused with hardening ----------------
  * replaces _MedianQueue.get_next/get_median/end   empanada/inference/engines.py:47-90

@@ -27,3 +27,31 @@ def dwconv_nhwc(x_nhwc, w_kkc, bias=None):
                                  b.ctypes.data_as(f32p) if b is not None else None, N, H, W, C, k,
                                  y.ctypes.data_as(f32p))
     return y
+
+
+def upsample_bilinear(x, size):
+    """bilinear, align_corners=True, (N,C,h,w) fp32 -> (N,C,H,W): restatement of what the reference's
+    F.interpolate(..., mode='bilinear', align_corners=True) computes (empanada/models/panoptic_deeplab.py:100-113,
+    decoders/panoptic_deeplab.py:70-78) with the operation order of include/emp_hip.h (D3) fixed; every numpy
+    fp32 operation is one rounding.  Pinned against torch's own interpolate within 1e-6 in the GPU tests."""
+    x = np.asarray(x, dtype=np.float32)
+    N, C, h, w = x.shape
+    H, W = size
+    f = np.float32
+
+    def src(n_in, n_out):
+        r = f(n_in - 1) / f(n_out - 1) if n_out > 1 else f(0)
+        s = (r * np.arange(n_out, dtype=np.float32)).astype(np.float32)
+        i0 = np.minimum(s.astype(np.int64), n_in - 1)
+        i1 = i0 + (i0 < n_in - 1)
+        return i0, i1, (s - i0.astype(np.float32)).astype(np.float32)
+
+    y0, y1, ly = src(h, H)
+    x0, x1, lx = src(w, W)
+    lx0, ly0 = (f(1) - lx).astype(np.float32), (f(1) - ly).astype(np.float32)
+    v00, v01 = x[:, :, y0][:, :, :, x0], x[:, :, y0][:, :, :, x1]
+    v10, v11 = x[:, :, y1][:, :, :, x0], x[:, :, y1][:, :, :, x1]
+    top = (lx0 * v00).astype(np.float32) + (lx * v01).astype(np.float32)
+    bot = (lx0 * v10).astype(np.float32) + (lx * v11).astype(np.float32)
+    lyc, ly0c = ly[:, None], ly0[:, None]
+    return ((ly0c * top).astype(np.float32) + (lyc * bot).astype(np.float32)).astype(np.float32)

@@ -433,3 +433,38 @@ def test_dwconv_argument_errors(hip):
     x = torch.zeros(1, 8, 4, 4, device='cuda').contiguous(memory_format=torch.channels_last)
     with pytest.raises(hip.HipError):
         hip.dwconv_nhwc(x, torch.zeros(49, 8, device='cuda'), None, 7)        # unsupported k
+
+
+@pytest.mark.parametrize('shape,size,layout', [((2, 1, 16, 16), (64, 64), 'nchw'), ((3, 2, 9, 7), (36, 28), 'nhwc'),
+                                                ((2, 8, 5, 6), (10, 12), 'nhwc'), ((1, 12, 1, 1), (4, 5), 'nhwc'),
+                                                ((2, 3, 7, 5), (7, 5), 'nchw'), ((1, 4, 6, 6), (11, 13), 'nchw')])
+def test_upsample_bilinear(hip, shape, size, layout):
+    """emp_upsample_bilinear: bit-exact against the numpy oracle; within 1e-6 * max|x| of torch's interpolate."""
+    from oracle import dense as OD
+    g = torch.Generator().manual_seed(sum(shape) + size[0])
+    x = torch.randn(*shape, generator=g)
+    xd = x.cuda()
+    if layout == 'nhwc':
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    got = hip.upsample_bilinear(xd, size)
+    exp = OD.upsample_bilinear(x.numpy(), size)
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    ref = torch.nn.functional.interpolate(x, size=size, mode='bilinear', align_corners=True)
+    assert (got.cpu() - ref).abs().max() <= 1e-6 * x.abs().max()
+    # into a channel slice of a wider channels_last buffer (the decoder's concat target)
+    N, C = shape[:2]
+    buf = torch.full((N, C + 4, size[0], size[1]), -7.0, device='cuda').contiguous(memory_format=torch.channels_last)
+    hip.upsample_bilinear(xd, size, out=buf[:, 4:])
+    np.testing.assert_array_equal(buf[:, 4:].cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    assert torch.all(buf[:, :4] == -7.0)
+
+
+def test_bn_act_into_channel_slice(hip):
+    x = torch.randn(2, 8, 5, 7).cuda().contiguous(memory_format=torch.channels_last)
+    sc, sh = torch.rand(8).cuda() + 0.5, torch.randn(8).cuda()
+    buf = torch.full((2, 20, 5, 7), -3.0, device='cuda').contiguous(memory_format=torch.channels_last)
+    exp = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    hip.bn_act_nhwc_(x.clone(memory_format=torch.channels_last), sc, sh, None, True, out=buf[:, 8:16])
+    assert torch.equal(buf[:, 8:16], exp) and torch.all(buf[:, :8] == -3.0) and torch.all(buf[:, 16:] == -3.0)
+    inplace = hip.bn_act_nhwc_(x.clone(memory_format=torch.channels_last), sc, sh, None, True)
+    assert torch.equal(inplace, exp)
