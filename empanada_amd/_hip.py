@@ -36,6 +36,7 @@ SIGNATURES = {
     'emp_bn_act_nhwc': (_I, [_P, _P, _P, _P, _I, _L, _I, _P, _L, _P]),
     'emp_dwconv_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'emp_upsample_bilinear': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
+    'emp_conv_bn_act_nhwc': (_I, [_P, _P, _P, _P, _P, _L, _I] + [_I] * 10 + [_P, _L, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
@@ -474,4 +475,32 @@ def upsample_bilinear(x, size, out=None):
     ys = (ctypes.c_int64 * 4)(*out.stride())
     call('emp_upsample_bilinear', x.data_ptr(), N, C, h, w, xs, out.data_ptr(), H, W, ys, stream(),
          alg_bytes=4 * (x.numel() + N * C * H * W))
+    return out
+
+
+def conv_bn_act_nhwc(x, w_okkc, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, dil=1, out=None):
+    """Fused convolution + per-channel affine + residual + ReLU on the fp32 matrix cores (emp_conv_bn_act_nhwc).
+    x: (N,Cin,H,W) fp32 channels_last; w_okkc: (Cout,KH,KW,Cin) contiguous; residual: (N,Cout,OH,OW) channels_last
+    (or a channel slice); out: optional (N,Cout,OH,OW) channel slice of a channels_last buffer."""
+    require_gpu()
+    N, Cin, H, W = x.shape
+    Cout, KH, KW, _ = w_okkc.shape
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+
+    def pixel_stride(t):
+        assert t.shape == (N, Cout, OH, OW) and t.dtype == torch.float32 and t.stride(1) == 1
+        ps = t.stride(3)
+        assert t.stride(2) == OW * ps and t.stride(0) == OH * OW * ps, "NHWC channel slice required"
+        return ps
+
+    if out is None:
+        out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    ops = pixel_stride(out)
+    rps = pixel_stride(residual) if residual is not None else 0
+    call('emp_conv_bn_act_nhwc', x.data_ptr(), _ptr(w_okkc), _ptr(scale), _ptr(shift),
+         residual.data_ptr() if residual is not None else None, rps, int(bool(relu)), N, H, W, Cin, Cout, KH, KW,
+         stride, pad, dil, out.data_ptr(), ops, stream(),
+         alg_bytes=4 * (x.numel() + w_okkc.numel() + N * Cout * OH * OW * (2 if residual is not None else 1)))
     return out

@@ -1,0 +1,295 @@
+// D4: implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) with the BatchNorm / residual /
+// ReLU epilogue fused into the accumulator write-back.  gfx950 only.
+//
+//   GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin.  NHWC activations make every K-slab (32 input
+//   channels of one filter tap) of an A row 128 contiguous bytes; weights are stored (Cout, KH, KW, Cin) so a B
+//   row's slab is contiguous as well.
+//   Block = 256 threads = 2x2 waves, block tile 128 (pixels) x 128 (couts) x 32 (K); each wave owns 64x64 =
+//   2x2 MFMA tiles of 32x32 (4 accumulators x 16 VGPRs).  Global -> registers -> LDS staging, two LDS buffers,
+//   one barrier per slab: the loads of slab s+1 are in flight while slab s runs its 64 MFMAs.
+//   LDS rows are padded to 36 floats: the 16-byte fragment reads of 16 consecutive lanes then cover all 64 banks
+//   exactly once.
+//   K order inside a slab: the MFMA k-step j (0..15) consumes channels j (lanes 0-31) and 16 + j (lanes 32-63),
+//   so a lane's 16 operands per slab are 64 contiguous bytes in LDS (four ds_read_b128) -- see emp_hip.h for the
+//   resulting summation order, which the oracle reproduces bit for bit.
+//   blockIdx -> tile: consecutive hardware block ids go to different XCDs; tiles are renumbered so that each XCD
+//   (its own L2) works on a contiguous range of tiles, cout-tiles fastest, and the A slabs shared by the cout
+//   tiles of one pixel tile are fetched once per XCD.
+#include "emp_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CG_BM 128
+#define CG_BK 32
+#define CG_LD 36          // padded LDS row (floats)
+#define CG_THREADS 256
+
+struct ConvGeom {
+    const float *x, *w, *scale, *shift, *res;
+    float *out;
+    int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, relu;
+    int64_t M, out_ps, res_ps;
+    int tiles_m, tiles_n;
+};
+
+// NT = 32-wide cout tiles per wave: block tile 128 x (64 * NT) (NT = 1 for layers with Cout <= 64)
+template <int NT>
+__global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom g)
+{
+    constexpr int BN = 64 * NT;
+    constexpr int BROWS = BN / 32;                 // B rows staged per thread
+    constexpr int CLD = BN + 4;                    // padded row of the epilogue staging tile (floats)
+    constexpr int A_ELEMS = 2 * CG_BM * CG_LD, B_ELEMS = 2 * BN * CG_LD, C_ELEMS = CG_BM * CLD;
+    constexpr int SMEM = (A_ELEMS + B_ELEMS) > C_ELEMS ? (A_ELEMS + B_ELEMS) : C_ELEMS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float *As = smem, *Bs = smem + A_ELEMS;
+
+    // XCD-aware tile numbering
+    const int T = g.tiles_m * g.tiles_n;
+    const int chunk = (T + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (tile >= T) return;
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const int64_t m0 = (int64_t)tm * CG_BM;
+    const int n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+
+    // the 4 A rows (output pixels) and BROWS B rows (couts) this thread stages, fixed over the K loop
+    int a_n[4], a_iy[4], a_ix[4];
+    bool a_ok[4], b_ok[BROWS];
+    const float *b_ptr[BROWS];
+    const int taps = g.KH * g.KW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t p = m0 + lrow + 32 * i;
+        a_ok[i] = p < g.M;
+        const int64_t pp = a_ok[i] ? p : 0;
+        const int ox = (int)(pp % g.OW);
+        const int oy = (int)((pp / g.OW) % g.OH);
+        a_n[i] = (int)(pp / ((int64_t)g.OW * g.OH));
+        a_iy[i] = oy * g.stride - g.pad;
+        a_ix[i] = ox * g.stride - g.pad;
+    }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+        const int co = n0 + lrow + 32 * i;
+        b_ok[i] = co < g.Cout;
+        b_ptr[i] = g.w + (int64_t)(b_ok[i] ? co : 0) * taps * g.Cin + lcol;    // row 0 stands in for rows past Cout
+    }
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int cslabs = g.Cin / CG_BK;
+    const int S = taps * cslabs;
+    float4 ra[4], rb[BROWS];
+
+    // Staging state of the NEXT slab to load: filter tap, channel offset, and per A row the source pointer of the
+    // tap (rows whose tap falls outside the image, or past M, read a dummy address and are zeroed after the load:
+    // no divergent branches around the loads).  Pointers are recomputed once per tap, not per slab.
+    int ld_tap = 0, ld_c0 = 0;
+    const float *a_ptr[4];
+    bool a_in[4];
+    auto set_tap = [&](int tap) {
+        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = a_iy[i] + ky * g.dil, ix = a_ix[i] + kx * g.dil;
+            a_in[i] = a_ok[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            a_ptr[i] = a_in[i] ? g.x + (((int64_t)a_n[i] * g.H + iy) * g.W + ix) * g.Cin + lcol : g.x + lcol;
+        }
+    };
+    set_tap(0);
+    auto load_slab = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_ptr[i] + ld_c0);
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const float4 *>(b_ptr[i] + (int64_t)ld_tap * g.Cin + ld_c0);
+        ld_c0 += CG_BK;
+        if (ld_c0 == g.Cin) {               // block-uniform
+            ld_c0 = 0;
+            ++ld_tap;
+            if (ld_tap < taps) set_tap(ld_tap);
+        }
+    };
+    // a_in of the slab held in ra: captured before load_slab advances the tap
+    bool r_in[4];
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = ra[i];
+            if (!r_in[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(&As[buf * CG_BM * CG_LD + (lrow + 32 * i) * CG_LD + lcol]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            float4 v = rb[i];
+            if (!b_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(&Bs[buf * BN * CG_LD + (lrow + 32 * i) * CG_LD + lcol]) = v;
+        }
+    };
+#define CG_LOAD_NEXT()                                   \
+    do {                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) r_in[i_] = a_in[i_]; \
+        load_slab();                                     \
+    } while (0)
+
+    // Pipeline: slab s is consumed from LDS buffer s & 1 while slab s+1 (already in registers, loaded one
+    // iteration earlier) is written to the other buffer between the MFMAs, and the global loads of slab s+2 are
+    // issued right behind it: a load has a whole iteration (64 MFMAs per wave) to land, and the LDS writes, address
+    // arithmetic and load issue all overlap the matrix pipe.
+    CG_LOAD_NEXT();
+    store_slab(0);
+    if (S > 1) CG_LOAD_NEXT();
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        const int buf = s & 1;
+        const float *Ab = &As[buf * CG_BM * CG_LD + (wm * 64 + r) * CG_LD + hh * 16];
+        const float *Bb = &Bs[buf * BN * CG_LD + (wn * 32 * NT + r) * CG_LD + hh * 16];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 fa[2][2], fb[NT][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    fa[i][q] = *reinterpret_cast<const float4 *>(Ab + i * 32 * CG_LD + half * 8 + q * 4);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    fb[j][q] = *reinterpret_cast<const float4 *>(Bb + j * 32 * CG_LD + half * 8 + q * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float av[2], bv[NT];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        av[i] = e == 0 ? fa[i][q].x : e == 1 ? fa[i][q].y : e == 2 ? fa[i][q].z : fa[i][q].w;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        bv[j] = e == 0 ? fb[j][q].x : e == 1 ? fb[j][q].y : e == 2 ? fb[j][q].z : fb[j][q].w;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+                if (half == 0 && q == 0) {
+                    if (s + 1 < S) store_slab(buf ^ 1);     // slab s+1: registers -> the buffer read in iteration s-1
+                    if (s + 2 < S) CG_LOAD_NEXT();          // slab s+2: global -> registers
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue, staged through LDS so that global traffic is 16 bytes per lane and row-contiguous:
+    // accumulators -> LDS tile [128][BN] (C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)),
+    // then y = relu?(acc * scale[co] + shift[co] (+ residual)) written as float4 along cout.
+    float *Cs = smem;                                  // the K loop ended with a barrier: As / Bs are free
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+                Cs[row * CLD + wn * 32 * NT + j * 32 + r] = acc[i][j][q];
+            }
+    __syncthreads();
+    constexpr int C4 = BN / 4;                         // float4 columns of the tile
+    constexpr int RPI = CG_THREADS / C4;               // rows per iteration
+    const int ccol = (tid % C4) * 4, crow = tid / C4;
+    const int co = n0 + ccol;
+    const bool vec_ok = (co + 3 < g.Cout) && ((g.out_ps & 3) == 0) && ((g.res_ps & 3) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) &&
+                        (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 15) == 0) && ((g.Cout & 3) == 0);
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (co + e < g.Cout) {
+            if (g.scale) sc[e] = g.scale[co + e];
+            if (g.shift) sh[e] = g.shift[co + e];
+        }
+#pragma unroll 4
+    for (int row = crow; row < CG_BM; row += RPI) {
+        const int64_t p = m0 + row;
+        if (p >= g.M) break;
+        const float4 a4 = *reinterpret_cast<const float4 *>(&Cs[row * CLD + ccol]);
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+        float rr[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.res) {
+            if (vec_ok) {
+                const float4 r4 = *reinterpret_cast<const float4 *>(g.res + p * g.res_ps + co);
+                rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (co + e < g.Cout) rr[e] = g.res[p * g.res_ps + co + e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (g.scale) v[e] = __fmul_rn(v[e], sc[e]);
+            if (g.shift) v[e] = __fadd_rn(v[e], sh[e]);
+            if (g.res) v[e] = __fadd_rn(v[e], rr[e]);
+            if (g.relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (vec_ok) {
+            *reinterpret_cast<float4 *>(g.out + p * g.out_ps + co) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (co + e < g.Cout) g.out[p * g.out_ps + co + e] = v[e];
+        }
+    }
+}
+
+extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
+                                    const float *residual, int64_t res_pixel_stride, int relu, int N, int H, int W,
+                                    int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float *out,
+                                    int64_t out_pixel_stride, void *stream)
+{
+    EMP_REQUIRE(x && w_okkc && out, "conv: null pointer");
+    EMP_REQUIRE(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv: bad shape");
+    EMP_REQUIRE(Cin % CG_BK == 0, "conv: Cin %d must be a multiple of %d", Cin, CG_BK);
+    EMP_REQUIRE(KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7 && stride >= 1 && dil >= 1 && pad >= 0, "conv: bad filter geometry");
+    const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+    const int OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    EMP_REQUIRE(OH > 0 && OW > 0, "conv: empty output");
+    if (out_pixel_stride == 0) out_pixel_stride = Cout;
+    if (res_pixel_stride == 0) res_pixel_stride = Cout;
+    EMP_REQUIRE(out_pixel_stride >= Cout && res_pixel_stride >= Cout, "conv: bad pixel stride");
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_okkc)) & 15) == 0,
+                "conv: x and w must be 16-byte aligned");
+    EMP_REQUIRE(out != x, "conv: output cannot alias the input");
+    if (N == 0) return EMP_OK;
+    ConvGeom g;
+    g.x = x; g.w = w_okkc; g.scale = scale; g.shift = shift; g.res = residual; g.out = out;
+    g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KH = KH; g.KW = KW;
+    g.stride = stride; g.pad = pad; g.dil = dil; g.relu = relu;
+    g.M = (int64_t)N * OH * OW; g.out_ps = out_pixel_stride; g.res_ps = res_pixel_stride;
+    const int64_t tiles_m = emp_cdiv(g.M, CG_BM);
+    const bool narrow = Cout <= 64 || (Cout % 128 != 0 && Cout % 128 <= 64 && Cout < 512);
+    g.tiles_n = (int)emp_cdiv(Cout, narrow ? 64 : 128);
+    EMP_REQUIRE(tiles_m * g.tiles_n < (1LL << 28), "conv: too many tiles");
+    g.tiles_m = (int)tiles_m;
+    const int T = g.tiles_m * g.tiles_n;
+    const int grid = 8 * ((T + 7) / 8);
+    if (narrow) hipLaunchKernelGGL((conv_igemm_f32_kernel<1>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+    EMP_CHECK_LAUNCH("emp_conv_bn_act_nhwc");
+    return EMP_OK;
+}

@@ -79,6 +79,24 @@ int emp_dwconv_nhwc(const float *x, const float *w_kkc, const float *bias, int N
 int emp_upsample_bilinear(const float *x, int N, int C, int h, int w, const int64_t *x_strides,
                           float *y, int H, int W, const int64_t *y_strides, void *stream);
 
+/* ---- D4: convolution + BatchNorm(eval) + residual + ReLU in one kernel, NHWC fp32, fp32 matrix cores -----
+ * replaces Conv2d -> BatchNorm2d -> (+ identity) -> ReLU chains of the dense path:
+ *          Bottleneck / BasicBlock forward         empanada/models/encoders/resnet.py:66-82,110-128
+ *          conv_bn_act, ASPP branches, projections empanada/models/blocks.py:121-171, decoders/aspp.py:22-102
+ * out[p, co] = act(acc[p, co] * scale[co] + shift[co] + residual[p, co]); scale / shift / residual optional (NULL),
+ * act = ReLU if relu != 0; acc = sum over taps (ky, kx) and input channels of x[n, oy*stride - pad + ky*dil,
+ * ox*stride - pad + kx*dil, c] * w_okkc[co, ky, kx, c], evaluated as ONE fp32 fma chain from +0 (the MFMA is
+ * bit-for-bit an fmaf chain): taps in raster order; per tap, slabs of 32 channels ascending; per slab the order
+ * c, c + 16 for c = 0..15; taps outside the image enter as x = 0.  The epilogue's multiply and adds are separate
+ * fp32 roundings, as in emp_bn_act_nhwc.
+ * x: (N, H, W, Cin), Cin % 32 == 0; w_okkc: (Cout, KH, KW, Cin) (the Conv2d weight permuted); residual and out
+ * are addressed as base + pixel * pixel_stride + co (stride 0 means Cout), so out may be a channel slice of a
+ * wider NHWC concat buffer.  x and w 16-byte aligned; out must not alias x.                                    */
+int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
+                         const float *residual, int64_t res_pixel_stride, int relu, int N, int H, int W,
+                         int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float *out,
+                         int64_t out_pixel_stride, void *stream);
+
 /* ---- P1 + P2: recursive median over a resident stack, fused with hardening ----------------
  * replaces _MedianQueue.get_next/get_median/end   empanada/inference/engines.py:47-90
  *          _harden_seg / harden_seg               engines.py:114-121, inference/patterns.py:242-251

@@ -44,5 +44,7 @@ def lib():
                                           i64p, ctypes.c_int64, ctypes.c_uint32]
         L.emp_oracle_dwconv_nhwc.restype = None
         L.emp_oracle_dwconv_nhwc.argtypes = [f32p, f32p, f32p] + [ctypes.c_int] * 5 + [f32p]
+        L.emp_oracle_conv_bn_act_nhwc.restype = None
+        L.emp_oracle_conv_bn_act_nhwc.argtypes = [f32p] * 5 + [ctypes.c_int] * 11 + [f32p]
         _lib = L
     return _lib

@@ -214,3 +214,42 @@ void emp_oracle_dwconv_nhwc(const float *x, const float *w_kkc, const float *bia
                     y[(((int64_t)n * H + r) * W + c) * C + ch] = acc + (bias ? bias[ch] : 0.0f);
                 }
 }
+
+/* Convolution + eval-BatchNorm affine + residual + ReLU on NHWC fp32 (Conv2d -> BatchNorm2d -> (+identity) -> ReLU,
+ * empanada/models/encoders/resnet.py:66-82,110-128; blocks.py:121-171).  The reference leaves the summation order
+ * to the backend; this restatement fixes it to the order include/emp_hip.h (D4) documents for the MFMA kernel:
+ * one fmaf chain from +0 over filter taps in raster order, per tap over slabs of 32 input channels, per slab in
+ * the order c, c+16 for c = 0..15; taps outside the image enter as 0.  w: (Cout, KH, KW, Cin). */
+void emp_oracle_conv_bn_act_nhwc(const float *x, const float *w, const float *scale, const float *shift,
+                                 const float *res, int relu, int N, int H, int W, int Cin, int Cout, int KH,
+                                 int KW, int stride, int pad, int dil, float *out)
+{
+    const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+    const int OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox) {
+                const int64_t p = ((int64_t)n * OH + oy) * OW + ox;
+                for (int co = 0; co < Cout; ++co) {
+                    float acc = 0.0f;
+                    for (int ky = 0; ky < KH; ++ky)
+                        for (int kx = 0; kx < KW; ++kx) {
+                            const int iy = oy * stride - pad + ky * dil, ix = ox * stride - pad + kx * dil;
+                            const int in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                            const float *xp = in ? x + (((int64_t)n * H + iy) * W + ix) * Cin : 0;
+                            const float *wp = w + (((int64_t)co * KH + ky) * KW + kx) * Cin;
+                            for (int c0 = 0; c0 < Cin; c0 += 32)
+                                for (int j = 0; j < 16; ++j) {
+                                    acc = fmaf(in ? xp[c0 + j] : 0.0f, wp[c0 + j], acc);
+                                    acc = fmaf(in ? xp[c0 + 16 + j] : 0.0f, wp[c0 + 16 + j], acc);
+                                }
+                        }
+                    float v = acc;
+                    if (scale) v = v * scale[co];
+                    if (shift) v = v + shift[co];
+                    if (res) v = v + res[p * Cout + co];
+                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    out[p * Cout + co] = v;
+                }
+            }
+}

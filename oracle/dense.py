@@ -55,3 +55,28 @@ def upsample_bilinear(x, size):
     bot = (lx0 * v10).astype(np.float32) + (lx * v11).astype(np.float32)
     lyc, ly0c = ly[:, None], ly0[:, None]
     return ((ly0c * top).astype(np.float32) + (lyc * bot).astype(np.float32)).astype(np.float32)
+
+
+def conv_bn_act_nhwc(x_nhwc, w_okkc, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, dil=1):
+    """x (N,H,W,Cin), w (Cout,KH,KW,Cin), per-channel scale/shift, residual (N,OH,OW,Cout) -> (N,OH,OW,Cout),
+    all fp32; summation order of include/emp_hip.h (D4).  Plain C (oracle/c/oracle_kernels.c)."""
+    x = np.ascontiguousarray(x_nhwc, dtype=np.float32)
+    w = np.ascontiguousarray(w_okkc, dtype=np.float32)
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    y = np.empty((N, OH, OW, Cout), dtype=np.float32)
+    f32p = ctypes.POINTER(ctypes.c_float)
+
+    def ptr(a):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return a, a.ctypes.data_as(f32p)
+
+    keep = [ptr(a) for a in (scale, shift, residual)]
+    lib().emp_oracle_conv_bn_act_nhwc(x.ctypes.data_as(f32p), w.ctypes.data_as(f32p), keep[0][1], keep[1][1],
+                                      keep[2][1], int(bool(relu)), N, H, W, Cin, Cout, KH, KW, stride, pad, dil,
+                                      y.ctypes.data_as(f32p))
+    return y

@@ -468,3 +468,50 @@ def test_bn_act_into_channel_slice(hip):
     assert torch.equal(buf[:, 8:16], exp) and torch.all(buf[:, :8] == -3.0) and torch.all(buf[:, 16:] == -3.0)
     inplace = hip.bn_act_nhwc_(x.clone(memory_format=torch.channels_last), sc, sh, None, True)
     assert torch.equal(inplace, exp)
+
+
+@pytest.mark.parametrize('cfg', [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, res, relu, affine
+    (2, 9, 11, 64, 128, 1, 1, 0, 1, True, True, True),
+    (1, 12, 10, 32, 40, 3, 1, 1, 1, False, True, True),        # Cout not a tile multiple
+    (2, 13, 13, 64, 256, 3, 1, 2, 2, False, True, True),       # dilated (ASPP / layer4)
+    (1, 16, 14, 96, 64, 3, 2, 1, 1, False, False, True),       # stride 2
+    (3, 7, 5, 32, 32, 1, 2, 0, 1, False, False, False),        # downsample-like, no epilogue
+    (1, 10, 10, 64, 130, 3, 1, 6, 6, True, False, True),       # dilation wider than the image border
+])
+def test_conv_bn_act_nhwc(hip, cfg):
+    """emp_conv_bn_act_nhwc: bit-exact against the C oracle (same fma chain); within fp32 rounding of torch's
+    conv2d + affine + residual + relu.  Tolerance vs torch: |err| <= 2e-6 * sum|x||w| * |scale| + 1e-6."""
+    from oracle import dense as OD
+    N, H, W, Cin, Cout, k, stride, pad, dil, use_res, relu, affine = cfg
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k) ** 0.5)
+    sc = torch.rand(Cout, generator=g) + 0.5 if affine else None
+    sh = torch.randn(Cout, generator=g) if affine else None
+    ref = torch.nn.functional.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    w_okkc = w.permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    resd = res.cuda().contiguous(memory_format=torch.channels_last) if use_res else None
+    got = hip.conv_bn_act_nhwc(xd, w_okkc.cuda(), sc.cuda() if affine else None, sh.cuda() if affine else None,
+                               resd, relu, stride, pad, dil)
+    exp = OD.conv_bn_act_nhwc(x.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), sc.numpy() if affine else None,
+                              sh.numpy() if affine else None,
+                              res.permute(0, 2, 3, 1).numpy() if use_res else None, relu, stride, pad, dil)
+    np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    bound = torch.nn.functional.conv2d(x.abs(), w.abs(), None, stride=stride, padding=pad, dilation=dil)
+    y = ref
+    if affine:
+        y = y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        bound = bound * sc.view(1, -1, 1, 1)
+    if use_res:
+        y = y + res
+    if relu:
+        y = torch.relu(y)
+    assert torch.all((got.cpu() - y).abs() <= 2e-6 * bound + 1e-6)
+    # into a channel slice of a wider buffer
+    buf = torch.full((N, Cout + 8, ref.shape[2], ref.shape[3]), 5.0, device='cuda').contiguous(memory_format=torch.channels_last)
+    hip.conv_bn_act_nhwc(xd, w_okkc.cuda(), sc.cuda() if affine else None, sh.cuda() if affine else None, resd, relu,
+                         stride, pad, dil, out=buf[:, 8:])
+    assert torch.equal(buf[:, 8:], got) and torch.all(buf[:, :8] == 5.0)
