@@ -53,7 +53,10 @@ PMC_TRAFFIC_BYTES_PER_VOXEL = {
 # same, as a ratio to the algorithmic bytes, for the dense-path kernels whose shapes vary from call to call
 # (profiles/r1_pmc_dense.md)
 PMC_TRAFFIC_RATIO = {'emp_bn_act_nhwc': None, 'emp_dwconv_nhwc': None}
-DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc')
+DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 'emp_conv_bn_act_nhwc',
+                 'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_output_transform')
+MFMA_KERNELS = ('emp_conv_bn_act_nhwc', 'emp_gemm_nt_batched')
+MFMA_F32_PEAK_TFLOPS = 157.3                   # dense fp32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -66,6 +69,7 @@ def parse():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--batch', type=int, default=32, help='slices per model call')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
+    ap.add_argument('--no-tune', action='store_true', help='keep MIOpen + epilogue pass for every convolution')
     ap.add_argument('--cpu-slices', type=int, default=96, help='slices of the same workload for the CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='run the passes strictly one after the other')
@@ -101,7 +105,23 @@ class Pipeline:
         self.device = device
         self.batch = args.batch
         self.timers = {}
+        self.tuned = {}
         self.post_stream = torch.cuda.Stream(device=device)
+
+    @torch.no_grad()
+    def tune(self, size):
+        """warm-up only: let every conv + BN call site pick its fastest implementation on the bench shapes"""
+        from empanada_amd.models import tune_fused_convs
+        if self.dtype != torch.float32:
+            return
+        x = torch.rand((self.batch, 1, size, size), device=self.device).contiguous(memory_format=torch.channels_last)
+        rep = tune_fused_convs(self.model, x)
+        counts = {}
+        for _, (best, _) in rep.items():
+            counts[best] = counts.get(best, 0) + 1
+        self.tuned = counts
+        saved = sum(t['miopen'] - min(t.values()) for _, t in rep.values())
+        log(f'conv call sites tuned: {counts}; isolated saving {saved:.2f} ms per batch of {self.batch}')
 
     @torch.no_grad()
     def forward(self, vol):
@@ -224,6 +244,8 @@ def main_orthoplane(args, device, rank, world):
     stacks, heads, n_obj, slice0 = build_inputs_ortho(S, device, rank, world)
     log(f'inputs ready ({n_obj} planted objects)')
     pipe = Pipeline(args, device)
+    if not args.no_tune:
+        pipe.tune(S)
     shape3d = (S, S, S)
     host_out = torch.empty(shape3d, dtype=torch.int32).pin_memory() if rank == 0 else None
 
@@ -352,6 +374,8 @@ def main():
     vol, heads, n_obj = build_inputs(D, S, device, seed_offset=rank)
     log(f'inputs ready ({n_obj} planted objects); building model')
     pipe = Pipeline(args, device)
+    if not args.no_tune:
+        pipe.tune(S)
     host_out = torch.empty((D, S, S), dtype=torch.int32).pin_memory()
     shape3d = (D, S, S)
 
@@ -438,29 +462,44 @@ def main():
         # per call (shapes vary by layer) and are sampled during the first timed pass.
         stat = {}
         for name, evs in prof.items():
-            ms = [a.elapsed_time(b) for a, b, _ in evs]
-            by = [nb if nb is not None else (ALG_BYTES[name](thing_frac) * vox if name in ALG_BYTES else None)
-                  for _, _, nb in evs]
+            ms = [e[0].elapsed_time(e[1]) for e in evs]
+            by = [e[2] if e[2] is not None else (ALG_BYTES[name](thing_frac) * vox if name in ALG_BYTES else None)
+                  for e in evs]
+            fl = [e[3] for e in evs]
             passes = 1 if (name in DENSE_KERNELS and not args.no_pipeline) else args.steps
             stat[name] = {'calls_per_pass': len(ms) / passes, 'ms_per_pass': float(np.sum(ms)) / passes,
                           'avg_ms': float(np.mean(ms)),
-                          'bytes': float(np.sum(by)) if all(b is not None for b in by) else None}
+                          'bytes': float(np.sum(by)) if all(b is not None for b in by) else None,
+                          'flops': float(np.sum(fl)) if all(f is not None for f in fl) else None}
         kern = {k: v['avg_ms'] for k, v in stat.items()}
         per_call = {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}
         per_pass = {k: round(v['ms_per_pass'], 3) for k, v in sorted(stat.items(), key=lambda kv: -kv[1]['ms_per_pass'])}
         roofs = {k: round(v['bytes'] / (v['avg_ms'] * len(prof[k]) * 1e-3) / 1e9, 1)
                  for k, v in stat.items() if v['bytes'] is not None}
-        # dominant hand-written kernel = most GPU time per pass among the calls with a byte model
+        tflops = {k: round(v['flops'] / (v['avg_ms'] * len(prof[k]) * 1e-3) / 1e12, 1)
+                  for k, v in stat.items() if v['flops'] is not None}
+        # dominant hand-written kernel = most GPU time per pass among the calls with a byte / flop model
         dom = max((k for k in stat if stat[k]['bytes'] is not None), key=lambda k: stat[k]['ms_per_pass'])
         n_dom = len(prof[dom])
         alg = stat[dom]['bytes'] / n_dom                                  # algorithmic bytes per launch (mean)
-        ach = roofs[dom]
         if dom in PMC_TRAFFIC_BYTES_PER_VOXEL:
             traffic = round(PMC_TRAFFIC_BYTES_PER_VOXEL[dom] * vox)
         elif PMC_TRAFFIC_RATIO.get(dom) is not None:
             traffic = round(PMC_TRAFFIC_RATIO[dom] * alg)
         else:
             traffic = None
+        if dom in MFMA_KERNELS:
+            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': tflops[dom], 'peak': MFMA_F32_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(tflops[dom] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+                    'alg_flops_per_launch': round(stat[dom]['flops'] / n_dom)}
+        else:
+            roof = {'bound': 'hbm', 'kernel': dom, 'achieved': roofs[dom], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(roofs[dom] / HBM_PEAK_GBS, 4), 'traffic': traffic}
+        roof.update({'alg_bytes_per_launch': round(alg), 'avg_launch_ms': round(kern[dom], 4),
+                     'launches_per_pass': stat[dom]['calls_per_pass'],
+                     'ms_per_pass': round(stat[dom]['ms_per_pass'], 3), 'thing_fraction': round(thing_frac, 4),
+                     'alg_bytes_per_voxel': {k: round(f(thing_frac), 3) for k, f in ALG_BYTES.items()},
+                     'all_kernels_GBps': roofs, 'mfma_kernels_TFLOPs': tflops})
         flops = 414477.0 * D * S * S                                      # PDL-R50, C=1
         res = {
             'metric': 'Mvox/s end-to-end 3D panoptic inference (incl. consensus); PQ vs CPU ref',
@@ -474,18 +513,11 @@ def main():
                        'objects_found': int(len(np.unique(host_out.numpy())) - 1)},
             'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'forward_end_to_slab_on_host': round(float(post_ms), 2),
                              'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2),
-                             'pipelined': not args.no_pipeline,
+                             'pipelined': not args.no_pipeline, 'conv_impls': pipe.tuned,
                              'host_chain_s': round(float(np.mean(pipe.timers.get('chain_s', [0]))), 4)},
             'hip_calls_ms': per_call,
             'hip_ms_per_pass': per_pass,
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'alg_bytes_per_launch': round(alg), 'avg_launch_ms': round(kern[dom], 4),
-                         'launches_per_pass': stat[dom]['calls_per_pass'],
-                         'ms_per_pass': round(stat[dom]['ms_per_pass'], 3),
-                         'thing_fraction': round(thing_frac, 4),
-                         'alg_bytes_per_voxel': {k: round(f(thing_frac), 3) for k, f in ALG_BYTES.items()},
-                         'all_kernels_GBps': roofs},
+            'roofline': roof,
         }
         if not args.no_cpu_baseline and world == 1:
             log('cpu baseline')

@@ -37,6 +37,9 @@ SIGNATURES = {
     'emp_dwconv_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'emp_upsample_bilinear': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     'emp_conv_bn_act_nhwc': (_I, [_P, _P, _P, _P, _P, _L, _I] + [_I] * 10 + [_P, _L, _P]),
+    'emp_wino_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
+    'emp_gemm_nt_batched': (_I, [_P, _P, _I, _L, _I, _I, _P, _P]),
+    'emp_wino_output_transform': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
@@ -120,14 +123,14 @@ def stream():
 
 
 # optional per-call HIP-event timing (bench.py): name -> list of (start_event, end_event, algorithmic bytes or
-# None).  Events are recorded on the stream the kernels are launched on (torch's current stream) and only read
+# None, algorithmic flops or None).  Events are recorded on the stream the kernels are launched on (torch's current stream) and only read
 # after the final sync.  Names in PROFILE_SKIP are not timed (bench.py samples the ~1600 dense-path calls of a
 # pass in one pass only, so that event packets do not perturb the others).
 PROFILE = None
 PROFILE_SKIP = set()
 
 
-def call(name, *args, alg_bytes=None):
+def call(name, *args, alg_bytes=None, alg_flops=None):
     """Call an int-returning ABI function; raise HipError with emp_last_error() on failure."""
     lib = load()
     if PROFILE is not None and name not in PROFILE_SKIP:
@@ -136,7 +139,7 @@ def call(name, *args, alg_bytes=None):
         e0.record()
         rc = getattr(lib, name)(*args)
         e1.record()
-        PROFILE.setdefault(name, []).append((e0, e1, alg_bytes))
+        PROFILE.setdefault(name, []).append((e0, e1, alg_bytes, alg_flops))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:
@@ -502,5 +505,70 @@ def conv_bn_act_nhwc(x, w_okkc, scale=None, shift=None, residual=None, relu=Fals
     call('emp_conv_bn_act_nhwc', x.data_ptr(), _ptr(w_okkc), _ptr(scale), _ptr(shift),
          residual.data_ptr() if residual is not None else None, rps, int(bool(relu)), N, H, W, Cin, Cout, KH, KW,
          stride, pad, dil, out.data_ptr(), ops, stream(),
-         alg_bytes=4 * (x.numel() + w_okkc.numel() + N * Cout * OH * OW * (2 if residual is not None else 1)))
+         alg_bytes=4 * (x.numel() + w_okkc.numel() + N * Cout * OH * OW * (2 if residual is not None else 1)),
+         alg_flops=2 * N * OH * OW * Cout * Cin * KH * KW)
+    return out
+
+
+def wino_tiles(N, H, W, dil):
+    """(T, 3) int32 numpy table of Winograd F(2x2,3x3) tiles for a 3x3 convolution with dilation dil and
+    padding dil: (n, y, x) of each tile's 4x4 patch origin, ordered (n, sub-grid row, sub-grid col, tile row, col)."""
+    import numpy as np
+    rows = []
+    for ry in range(min(dil, H)):
+        hs = -(-(H - ry) // dil)
+        for ty in range(-(-hs // 2)):
+            rows.append(ry + dil * (2 * ty - 1))
+    cols = []
+    for rx in range(min(dil, W)):
+        ws = -(-(W - rx) // dil)
+        for tx in range(-(-ws // 2)):
+            cols.append(rx + dil * (2 * tx - 1))
+    # group by sub-grid: rows are already grouped by ry, cols by rx
+    ys, xs = np.meshgrid(np.array(rows, dtype=np.int32), np.array(cols, dtype=np.int32), indexing='ij')
+    per = np.stack([ys.ravel(), xs.ravel()], axis=1)
+    out = np.empty((N, len(per), 3), dtype=np.int32)
+    out[:, :, 0] = np.arange(N, dtype=np.int32)[:, None]
+    out[:, :, 1:] = per[None]
+    return out.reshape(-1, 3)
+
+
+def wino_filter_transform(w_oihw):
+    """(Cout, Cin, 3, 3) -> U (16, Cout, Cin) = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], every step one
+    fp32 rounding: rows first (r1 = 0.5 * ((g0 + g1) + g2), r2 = 0.5 * ((g0 - g1) + g2)), then columns likewise."""
+    g = w_oihw.detach().float()
+
+    def comb(a, b, c):
+        return [a, 0.5 * ((a + b) + c), 0.5 * ((a - b) + c), c]
+
+    rows = comb(g[:, :, 0, :], g[:, :, 1, :], g[:, :, 2, :])              # 4 x (Cout, Cin, 3)
+    U = []
+    for rrow in rows:
+        U.extend(comb(rrow[:, :, 0], rrow[:, :, 1], rrow[:, :, 2]))       # 4 x (Cout, Cin)
+    return torch.stack(U, dim=0).contiguous()
+
+
+def wino_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, out=None):
+    """3x3 stride-1 convolution with padding == dilation through Winograd F(2x2,3x3) (emp_wino_input_transform,
+    emp_gemm_nt_batched, emp_wino_output_transform).  x (N,Cin,H,W) fp32 channels_last; U from
+    wino_filter_transform; tiles_dev = torch.from_numpy(wino_tiles(N,H,W,dil)).cuda()."""
+    require_gpu()
+    N, Cin, H, W = x.shape
+    Cout = U.shape[1]
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    T = tiles_dev.shape[0]
+    V = torch.empty((16, T, Cin), dtype=torch.float32, device=x.device)
+    Mw = torch.empty((16, T, Cout), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    assert out.shape == (N, Cout, H, W) and out.stride(1) == 1
+    ops = out.stride(3)
+    assert out.stride(2) == W * ops and out.stride(0) == H * W * ops, "NHWC channel slice required"
+    st = stream()
+    call('emp_wino_input_transform', x.data_ptr(), N, H, W, Cin, dil, _ptr(tiles_dev), T, _ptr(V), st,
+         alg_bytes=4 * (x.numel() + V.numel()))
+    call('emp_gemm_nt_batched', _ptr(V), _ptr(U), 16, T, Cout, Cin, _ptr(Mw), st,
+         alg_bytes=4 * (V.numel() + U.numel() + Mw.numel()), alg_flops=2 * 16 * T * Cout * Cin)
+    call('emp_wino_output_transform', _ptr(Mw), _ptr(tiles_dev), T, N, H, W, Cout, dil, _ptr(scale), _ptr(shift),
+         int(bool(relu)), out.data_ptr(), ops, st, alg_bytes=4 * (Mw.numel() + N * Cout * H * W))
     return out

@@ -30,6 +30,7 @@ struct ConvGeom {
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, relu;
     int64_t M, out_ps, res_ps;
     int tiles_m, tiles_n;
+    int64_t x_bs, w_bs, out_bs;      // blockIdx.y batches (Winograd positions): element strides of x, w, out
 };
 
 // NT = 32-wide cout tiles per wave: block tile 128 x (64 * NT) (NT = 1 for layers with Cout <= 64)
@@ -43,6 +44,9 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
     constexpr int SMEM = (A_ELEMS + B_ELEMS) > C_ELEMS ? (A_ELEMS + B_ELEMS) : C_ELEMS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float *As = smem, *Bs = smem + A_ELEMS;
+    g.x += (int64_t)blockIdx.y * g.x_bs;
+    g.w += (int64_t)blockIdx.y * g.w_bs;
+    g.out += (int64_t)blockIdx.y * g.out_bs;
 
     // XCD-aware tile numbering
     const int T = g.tiles_m * g.tiles_n;
@@ -281,6 +285,7 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KH = KH; g.KW = KW;
     g.stride = stride; g.pad = pad; g.dil = dil; g.relu = relu;
     g.M = (int64_t)N * OH * OW; g.out_ps = out_pixel_stride; g.res_ps = res_pixel_stride;
+    g.x_bs = g.w_bs = g.out_bs = 0;
     const int64_t tiles_m = emp_cdiv(g.M, CG_BM);
     const bool narrow = Cout <= 64 || (Cout % 128 != 0 && Cout % 128 <= 64 && Cout < 512);
     g.tiles_n = (int)emp_cdiv(Cout, narrow ? 64 : 128);
@@ -291,5 +296,160 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     if (narrow) hipLaunchKernelGGL((conv_igemm_f32_kernel<1>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
     else hipLaunchKernelGGL((conv_igemm_f32_kernel<2>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
     EMP_CHECK_LAUNCH("emp_conv_bn_act_nhwc");
+    return EMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// D5: Winograd F(2x2, 3x3) for the 3x3 (dilated) stride-1 "same" convolutions with many input channels (ASPP,
+// layer4): 2.25x fewer matrix-core FLOPs than the direct form.  A dilated convolution is d*d independent plain
+// 3x3 convolutions on the sub-grids (y mod d, x mod d); each 2x2 output tile of a sub-grid needs a 4x4 input patch
+// with pixel spacing d.  Three steps: input transform V = B^T d B (this file), 16 GEMMs M_p = V_p U_p^T on the
+// fp32 matrix cores (conv_igemm_f32_kernel, blockIdx.y = position p), output transform Y = A^T M A fused with the
+// BatchNorm / ReLU epilogue.  tiles: (T, 3) int32 = (image n, y, x of the patch's top-left pixel), built by the host.
+
+// x (N,H,W,C) -> V (16, T, C); one thread per (tile, 4 channels)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, const int32_t *__restrict__ tiles,
+                                                         int64_t T, int H, int W, int C4, int dil, float4 *__restrict__ V)
+{
+    const int64_t total = T * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const int64_t t = i / C4;
+        const int n = tiles[3 * t], by = tiles[3 * t + 1], bx = tiles[3 * t + 2];
+        const float4 *src = reinterpret_cast<const float4 *>(x) + (int64_t)n * H * W * C4 + c4;
+        float4 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int yy = by + a * dil, xx = bx + b * dil;
+                d[a][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) d[a][b] = src[((int64_t)yy * W + xx) * C4];
+            }
+#define W_SUB(p, q) make_float4(__fsub_rn(p.x, q.x), __fsub_rn(p.y, q.y), __fsub_rn(p.z, q.z), __fsub_rn(p.w, q.w))
+#define W_ADD(p, q) make_float4(__fadd_rn(p.x, q.x), __fadd_rn(p.y, q.y), __fadd_rn(p.z, q.z), __fadd_rn(p.w, q.w))
+        float4 tt[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {          // along columns: t[a] = d[a] B
+            tt[a][0] = W_SUB(d[a][0], d[a][2]);
+            tt[a][1] = W_ADD(d[a][1], d[a][2]);
+            tt[a][2] = W_SUB(d[a][2], d[a][1]);
+            tt[a][3] = W_SUB(d[a][1], d[a][3]);
+        }
+        float4 *dst = V + t * C4 + c4;
+        const int64_t ps = T * C4;             // position stride
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {          // along rows: V = B^T t
+            dst[(0 * 4 + v) * ps] = W_SUB(tt[0][v], tt[2][v]);
+            dst[(1 * 4 + v) * ps] = W_ADD(tt[1][v], tt[2][v]);
+            dst[(2 * 4 + v) * ps] = W_SUB(tt[2][v], tt[1][v]);
+            dst[(3 * 4 + v) * ps] = W_SUB(tt[1][v], tt[3][v]);
+        }
+    }
+}
+
+// Mw (16, T, Cout) -> out (N,H,W,Cout) with the fused epilogue; one thread per (tile, 4 couts)
+__global__ __launch_bounds__(256) void wino_output_kernel(const float4 *__restrict__ Mw, const int32_t *__restrict__ tiles,
+                                                          int64_t T, int H, int W, int Co4, int dil,
+                                                          const float4 *__restrict__ scale, const float4 *__restrict__ shift,
+                                                          int relu, float *__restrict__ out, int64_t out_ps)
+{
+    const int64_t total = T * Co4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % Co4);
+        const int64_t t = i / Co4;
+        const int n = tiles[3 * t], oy = tiles[3 * t + 1] + dil, ox = tiles[3 * t + 2] + dil;
+        const float4 *src = Mw + t * Co4 + c4;
+        const int64_t ps = T * Co4;
+        float4 m[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m[a][b] = src[(a * 4 + b) * ps];
+        float4 s[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {          // rows: s = A^T m
+            s[0][b] = W_ADD(W_ADD(m[0][b], m[1][b]), m[2][b]);
+            s[1][b] = W_SUB(W_SUB(m[1][b], m[2][b]), m[3][b]);
+        }
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) sc = scale[c4];
+        if (shift) sh = shift[c4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float4 yv[2];
+            yv[0] = W_ADD(W_ADD(s[a][0], s[a][1]), s[a][2]);      // columns: y = s A
+            yv[1] = W_SUB(W_SUB(s[a][1], s[a][2]), s[a][3]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int yy = oy + a * dil, xx = ox + b * dil;
+                if (yy < H && xx < W) {
+                    float4 v = yv[b];
+                    if (scale) v = make_float4(__fmul_rn(v.x, sc.x), __fmul_rn(v.y, sc.y), __fmul_rn(v.z, sc.z), __fmul_rn(v.w, sc.w));
+                    if (shift) v = W_ADD(v, sh);
+                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    *reinterpret_cast<float4 *>(out + (((int64_t)n * H + yy) * W + xx) * out_ps + 4 * c4) = v;
+                }
+            }
+        }
+    }
+}
+#undef W_SUB
+#undef W_ADD
+
+extern "C" int emp_wino_input_transform(const float *x, int N, int H, int W, int C, int dil, const int32_t *tiles,
+                                        int64_t T, float *V, void *stream)
+{
+    EMP_REQUIRE(x && tiles && V, "wino_input: null pointer");
+    EMP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && dil >= 1 && T >= 0, "wino_input: bad shape");
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(V)) & 15) == 0, "wino_input: alignment");
+    if (T == 0) return EMP_OK;
+    hipLaunchKernelGGL(wino_input_kernel, dim3(emp_grid(T * (C / 4), 256, 16384)), dim3(256), 0, emp_stream(stream), x,
+                       tiles, T, H, W, C / 4, dil, reinterpret_cast<float4 *>(V));
+    EMP_CHECK_LAUNCH("emp_wino_input_transform");
+    return EMP_OK;
+}
+
+extern "C" int emp_gemm_nt_batched(const float *A, const float *B, int batch, int64_t M, int N, int K, float *C,
+                                   void *stream)
+{
+    EMP_REQUIRE(A && B && C, "gemm: null pointer");
+    EMP_REQUIRE(batch >= 1 && batch <= 65535 && M >= 0 && M < (1LL << 31) && N > 0 && K > 0 && K % CG_BK == 0,
+                "gemm: bad shape (K must be a multiple of %d)", CG_BK);
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0, "gemm: alignment");
+    if (M == 0) return EMP_OK;
+    ConvGeom g;
+    g.x = A; g.w = B; g.scale = g.shift = g.res = nullptr; g.out = C;
+    g.N = 1; g.H = 1; g.W = (int)M; g.Cin = K; g.OH = 1; g.OW = (int)M; g.Cout = N; g.KH = g.KW = 1;
+    g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
+    g.M = M; g.out_ps = N; g.res_ps = N;
+    g.x_bs = M * K; g.w_bs = (int64_t)N * K; g.out_bs = M * N;
+    const bool narrow = N <= 64;
+    g.tiles_m = (int)emp_cdiv(M, CG_BM);
+    g.tiles_n = (int)emp_cdiv(N, narrow ? 64 : 128);
+    const int T = g.tiles_m * g.tiles_n;
+    dim3 grid(8 * ((T + 7) / 8), batch);
+    if (narrow) hipLaunchKernelGGL((conv_igemm_f32_kernel<1>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+    EMP_CHECK_LAUNCH("emp_gemm_nt_batched");
+    return EMP_OK;
+}
+
+extern "C" int emp_wino_output_transform(const float *Mw, const int32_t *tiles, int64_t T, int N, int H, int W,
+                                         int Cout, int dil, const float *scale, const float *shift, int relu,
+                                         float *out, int64_t out_pixel_stride, void *stream)
+{
+    EMP_REQUIRE(Mw && tiles && out, "wino_output: null pointer");
+    EMP_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0 && dil >= 1 && T >= 0, "wino_output: bad shape");
+    if (out_pixel_stride == 0) out_pixel_stride = Cout;
+    EMP_REQUIRE(out_pixel_stride >= Cout && out_pixel_stride % 4 == 0, "wino_output: bad pixel stride");
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(Mw) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(scale) |
+                  reinterpret_cast<uintptr_t>(shift)) & 15) == 0, "wino_output: alignment");
+    if (T == 0) return EMP_OK;
+    hipLaunchKernelGGL(wino_output_kernel, dim3(emp_grid(T * (Cout / 4), 256, 16384)), dim3(256), 0, emp_stream(stream),
+                       reinterpret_cast<const float4 *>(Mw), tiles, T, H, W, Cout / 4, dil,
+                       reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift), relu, out,
+                       out_pixel_stride);
+    EMP_CHECK_LAUNCH("emp_wino_output_transform");
     return EMP_OK;
 }

@@ -6,7 +6,7 @@ The conv stacks stay in PyTorch-ROCm (MIOpen / hipBLASLt on MFMA); see ``prepare
 """
 from .panoptic_bifpn import PanopticBiFPN, PanopticBiFPNPR
 from .panoptic_deeplab import (PanopticDeepLab, PanopticDeepLabPR, fuse_bn_act, prepare_for_inference,
-                               synthesize_weights)
+                               synthesize_weights, tune_fused_convs)
 
 __all__ = ['PanopticDeepLab', 'PanopticDeepLabPR', 'PanopticBiFPN', 'PanopticBiFPNPR', 'prepare_for_inference',
-           'synthesize_weights', 'fuse_bn_act']
+           'synthesize_weights', 'fuse_bn_act', 'tune_fused_convs']

@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 __all__ = ['PanopticDeepLab', 'PanopticDeepLabPR', 'PointRendSemSegHead', 'resnet_encoder', 'prepare_for_inference',
+           'tune_fused_convs',
            'synthesize_weights']
 
 _RESNETS = {
@@ -108,6 +109,73 @@ class FusedBNAct(nn.Module):
         return _hip.bn_act_nhwc_(x, self.scale, self.shift, residual, self.relu, out)
 
 
+class FusedConvBNAct(nn.Module):
+    """Conv2d + FusedBNAct (+ residual) as one call with three interchangeable implementations:
+      'miopen' : MIOpen convolution, then the emp_bn_act_nhwc epilogue pass              (default)
+      'direct' : emp_conv_bn_act_nhwc -- implicit GEMM on the fp32 matrix cores, epilogue fused
+      'wino'   : Winograd F(2x2,3x3) -- emp_wino_input_transform / emp_gemm_nt_batched / emp_wino_output_transform
+    tune_fused_convs() times the candidates on the layer's real shape and keeps the fastest."""
+
+    def __init__(self, conv, bn):
+        super().__init__()
+        self.conv, self.bn = conv, bn
+        self.impl = 'miopen'
+        self.tuned = {}
+        self._seen = None
+        self._w_okkc = None
+        self._U = None
+        self._tiles = {}
+
+    def candidates(self, has_residual):
+        c = self.conv
+        out = ['miopen']
+        plain = (c.groups == 1 and c.bias is None and c.padding_mode == 'zeros' and c.in_channels % 32 == 0
+                 and c.kernel_size[0] == c.kernel_size[1] and c.stride[0] == c.stride[1]
+                 and c.padding[0] == c.padding[1] and c.dilation[0] == c.dilation[1] and c.weight.dtype == torch.float32)
+        if plain:
+            out.append('direct')
+            if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == c.dilation and c.out_channels % 4 == 0
+                    and not has_residual):
+                out.append('wino')
+        return out
+
+    def _prepare(self, impl):
+        from .. import _hip
+        if impl == 'direct' and self._w_okkc is None:
+            self._w_okkc = self.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+        if impl == 'wino' and self._U is None:
+            self._U = _hip.wino_filter_transform(self.conv.weight.detach())
+
+    def release(self, keep):
+        if keep != 'direct':
+            self._w_okkc = None
+        if keep != 'wino':
+            self._U = None
+            self._tiles = {}
+
+    def forward(self, x, residual=None, out=None):
+        self._seen = (tuple(x.shape), residual is not None)
+        impl = self.impl
+        if impl == 'miopen' or not (x.is_cuda and x.dtype == torch.float32):
+            return self.bn(self.conv(x), residual, out)
+        from .. import _hip
+        c = self.conv
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        self._prepare(impl)
+        if impl == 'direct':
+            if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+                residual = residual.contiguous(memory_format=torch.channels_last)
+            return _hip.conv_bn_act_nhwc(x, self._w_okkc, self.bn.scale, self.bn.shift, residual, self.bn.relu,
+                                         c.stride[0], c.padding[0], c.dilation[0], out)
+        assert residual is None
+        key = (x.shape[0], x.shape[2], x.shape[3])
+        if key not in self._tiles:
+            self._tiles[key] = torch.from_numpy(_hip.wino_tiles(key[0], key[1], key[2], c.dilation[0])).to(x.device)
+        return _hip.wino_conv_bn_act(x, self._U, self._tiles[key], c.dilation[0], self.bn.scale, self.bn.shift,
+                                     self.bn.relu, out)
+
+
 def _up_bilinear(x, size, hip_ops, out=None):
     """F.interpolate(mode='bilinear', align_corners=True), through emp_upsample_bilinear when hip_ops"""
     if hip_ops and x.is_cuda and x.dtype == torch.float32:
@@ -123,15 +191,18 @@ def _up_bilinear(x, size, hip_ops, out=None):
 def _conv_bn_into(seq, x, out):
     """seq = Sequential(Conv2d, FusedBNAct(+ReLU), Identity...): the fused epilogue writes straight into `out`,
     a channel slice of the caller's concat buffer"""
-    y = seq[0](x)
-    seq[1](y, out=out)
+    if isinstance(seq[0], FusedConvBNAct):
+        seq[0](x, out=out)
+    else:
+        seq[1](seq[0](x), out=out)
     for extra in list(seq)[2:]:
         assert isinstance(extra, (nn.Identity, nn.Dropout)), "unexpected module after the fused epilogue"
 
 
 def _can_write_into(seq, x):
-    return (isinstance(seq, nn.Sequential) and len(seq) >= 2 and isinstance(seq[0], nn.Conv2d)
-            and isinstance(seq[1], FusedBNAct) and x.is_cuda and x.dtype == torch.float32)
+    if not (isinstance(seq, nn.Sequential) and len(seq) >= 2 and x.is_cuda and x.dtype == torch.float32):
+        return False
+    return isinstance(seq[0], FusedConvBNAct) or (isinstance(seq[0], nn.Conv2d) and isinstance(seq[1], FusedBNAct))
 
 
 class _Basic(nn.Module):
@@ -148,6 +219,8 @@ class _Basic(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
+        if isinstance(self.conv1, FusedConvBNAct):
+            return self.conv2(self.conv1(x), idt)
         if isinstance(self.bn1, FusedBNAct):
             out = self.bn1(self.conv1(x))
             return self.bn2(self.conv2(out), idt)
@@ -173,6 +246,8 @@ class _Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
+        if isinstance(self.conv1, FusedConvBNAct):
+            return self.conv3(self.conv2(self.conv1(x)), idt)
         if isinstance(self.bn1, FusedBNAct):
             out = self.bn2(self.conv2(self.bn1(self.conv1(x))))
             return self.bn3(self.conv3(out), idt)
@@ -304,7 +379,8 @@ class PanopticDeepLabDecoder(nn.Module):
             feat = pyramid[stage]
             if self.hip_ops and _can_write_into(proj, feat):
                 # up-sampled x and the projected low-level features land directly in the concat buffer
-                cx, cl = x.shape[1], proj[0].out_channels
+                cx = x.shape[1]
+                cl = (proj[0].conv if isinstance(proj[0], FusedConvBNAct) else proj[0]).out_channels
                 buf = torch.empty((x.shape[0], cx + cl, feat.shape[2], feat.shape[3]), dtype=x.dtype,
                                   device=x.device, memory_format=torch.channels_last)
                 _up_bilinear(x, feat.shape[2:], True, out=buf[:, :cx])
@@ -510,6 +586,61 @@ def fuse_bn_act(model):
     return model
 
 
+def pair_conv_bn(model):
+    """After fuse_bn_act: wrap every (Conv2d, FusedBNAct) producer/epilogue pair into one FusedConvBNAct call site
+    (ResNet blocks, Sequential[Conv2d, FusedBNAct, ...], and the pointwise conv of a separable conv + its BN)."""
+    for m in list(model.modules()):
+        if isinstance(m, (_Basic, _Bottleneck)):
+            for cn, bn_name in (('conv1', 'bn1'), ('conv2', 'bn2'), ('conv3', 'bn3')):
+                if hasattr(m, cn) and isinstance(getattr(m, cn), nn.Conv2d) and isinstance(getattr(m, bn_name), FusedBNAct):
+                    setattr(m, cn, FusedConvBNAct(getattr(m, cn), getattr(m, bn_name)))
+                    setattr(m, bn_name, nn.Identity())
+        elif isinstance(m, nn.Sequential):
+            for i in range(len(m) - 1):
+                if isinstance(m[i], nn.Conv2d) and isinstance(m[i + 1], FusedBNAct):
+                    m[i] = FusedConvBNAct(m[i], m[i + 1])
+                    m[i + 1] = nn.Identity()
+                elif (isinstance(m[i], SeparableConv2d) and isinstance(m[i + 1], FusedBNAct)
+                      and isinstance(m[i].sepconv[1], nn.Conv2d)):
+                    m[i].sepconv[1] = FusedConvBNAct(m[i].sepconv[1], m[i + 1])
+                    m[i + 1] = nn.Identity()
+    return model
+
+
+@torch.no_grad()
+def tune_fused_convs(model, example, reps=5, verbose=False):
+    """Pick, per FusedConvBNAct call site, the fastest of its implementations on the shapes `example` produces
+    (isolated timing with HIP events).  Returns {module name: (chosen, {impl: ms})}."""
+    model(example)                                   # records the shapes (and lets MIOpen pick its kernels)
+    report = {}
+    for name, m in model.named_modules():
+        if not isinstance(m, FusedConvBNAct) or m._seen is None:
+            continue
+        shape, has_res = m._seen
+        x = torch.randn(shape, device=example.device).contiguous(memory_format=torch.channels_last)
+        m.impl = 'miopen'
+        res = torch.randn_like(m(x)) if has_res else None
+        times = {}
+        for impl in m.candidates(has_res):
+            m.impl = impl
+            for _ in range(2):
+                m(x, res)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                m(x, res)
+            e1.record()
+            torch.cuda.synchronize()
+            times[impl] = e0.elapsed_time(e1) / reps
+        best = min(times, key=times.get)
+        m.impl, m.tuned = best, times
+        m.release(best)
+        report[name] = (best, {k: round(v, 4) for k, v in times.items()})
+        if verbose:
+            print(f"{name:55s} {shape} res={has_res} -> {best} {report[name][1]}", flush=True)
+    return report
+
+
 def swap_depthwise(model):
     """Swap every stride-1 depthwise Conv2d (3x3 / 5x5, zero "same" padding) for DepthwiseConvNHWC."""
     for m in model.modules():
@@ -532,7 +663,7 @@ def prepare_for_inference(model, device='cuda', dtype=torch.float32, channels_la
     if dtype != torch.float32:
         model = model.to(dtype)
     elif fuse and channels_last and torch.device(device).type == 'cuda':
-        model = swap_depthwise(fuse_bn_act(model))
+        model = swap_depthwise(pair_conv_bn(fuse_bn_act(model)))
         for m in model.modules():
             if hasattr(m, 'hip_ops'):
                 m.hip_ops = True                  # emp_upsample_bilinear + concat buffers written in place

@@ -97,6 +97,31 @@ int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale
                          int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float *out,
                          int64_t out_pixel_stride, void *stream);
 
+/* ---- D5: Winograd F(2x2, 3x3) convolution in three calls (3x3, stride 1, padding == dilation) ---------
+ * replaces the dilated 3x3 Conv2d -> BatchNorm2d -> ReLU of ASPP and of the dilated ResNet stage
+ *          (empanada/models/decoders/aspp.py:22-46, encoders/resnet.py:110-128) where Cin is large.
+ * A convolution with dilation d is d*d plain 3x3 convolutions on the sub-grids (y mod d, x mod d); a tile is a
+ * 2x2 block of outputs of one sub-grid and reads a 4x4 patch with pixel spacing d.
+ * tiles (DEVICE, (T, 3) int32): image index n and (y, x) of the patch's top-left pixel (may be negative: padding);
+ *   its outputs are the pixels (y + d + a*d, x + d + b*d), a, b in {0, 1}, that lie inside the image.
+ * 1. emp_wino_input_transform: V[p = 4*u + v, t, c] = (B^T patch B)[u, v], B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0;
+ *    0 1 0 -1], evaluated as: columns first (t_a0 = d_a0 - d_a2, t_a1 = d_a1 + d_a2, t_a2 = d_a2 - d_a1,
+ *    t_a3 = d_a1 - d_a3), then the same combination over rows.  x (N,H,W,C) fp32, V (16, T, C).
+ * 2. emp_gemm_nt_batched: C[b] (M, N) = A[b] (M, K) * B[b] (N, K)^T for b < batch, on the fp32 matrix cores with
+ *    the fma-chain order of emp_conv_bn_act_nhwc (slabs of 32, order c, c+16).  Here M = T, K = Cin, N = Cout,
+ *    batch = 16, B = the transformed filters U[p, co, c] = (G g G^T)[u, v] prepared by the host.
+ * 3. emp_wino_output_transform: Y = A^T M A per tile, A^T = [1 1 1 0; 0 1 -1 -1], rows first
+ *    (s_0 = (m_0 + m_1) + m_2, s_1 = (m_1 - m_2) - m_3), then columns likewise; then the epilogue of
+ *    emp_bn_act_nhwc (scale, shift optional) and the scatter to out (N,H,W,Cout), pixel stride out_pixel_stride
+ *    (0 means Cout).                                                                                          */
+int emp_wino_input_transform(const float *x, int N, int H, int W, int C, int dil, const int32_t *tiles,
+                             int64_t T, float *V, void *stream);
+int emp_gemm_nt_batched(const float *A, const float *B, int batch, int64_t M, int N, int K, float *C,
+                        void *stream);
+int emp_wino_output_transform(const float *Mw, const int32_t *tiles, int64_t T, int N, int H, int W,
+                              int Cout, int dil, const float *scale, const float *shift, int relu,
+                              float *out, int64_t out_pixel_stride, void *stream);
+
 /* ---- P1 + P2: recursive median over a resident stack, fused with hardening ----------------
  * replaces _MedianQueue.get_next/get_median/end   empanada/inference/engines.py:47-90
  *          _harden_seg / harden_seg               engines.py:114-121, inference/patterns.py:242-251

@@ -80,3 +80,62 @@ def conv_bn_act_nhwc(x_nhwc, w_okkc, scale=None, shift=None, residual=None, relu
                                       keep[2][1], int(bool(relu)), N, H, W, Cin, Cout, KH, KW, stride, pad, dil,
                                       y.ctypes.data_as(f32p))
     return y
+
+
+def wino_filter_transform(w_oihw):
+    """U (16, Cout, Cin) = G g G^T in the operation order of empanada_amd._hip.wino_filter_transform (numpy fp32)."""
+    g = np.asarray(w_oihw, dtype=np.float32)
+    h = np.float32(0.5)
+
+    def comb(a, b, c):
+        return [a, (h * ((a + b) + c)).astype(np.float32), (h * ((a - b) + c)).astype(np.float32), c]
+
+    rows = comb(g[:, :, 0, :], g[:, :, 1, :], g[:, :, 2, :])
+    U = []
+    for r in rows:
+        U.extend(comb(r[:, :, 0], r[:, :, 1], r[:, :, 2]))
+    return np.ascontiguousarray(np.stack(U, axis=0), dtype=np.float32)
+
+
+def wino_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=False):
+    """Winograd F(2x2,3x3) convolution exactly as include/emp_hip.h (D5) specifies it: input transform (numpy fp32,
+    one rounding per add), 16 GEMMs through the C fma-chain oracle, output transform + epilogue.  Pinned against
+    torch's conv2d within a stated tolerance in the GPU tests (the Winograd form is this framework's choice; the
+    reference calls the backend's convolution)."""
+    x = np.asarray(x_nhwc, dtype=np.float32)
+    N, H, W, C = x.shape
+    U = wino_filter_transform(w_oihw)
+    Cout = U.shape[1]
+    T = len(tiles)
+    xp = np.zeros((N, H + 6 * dil + 8, W + 6 * dil + 8, C), dtype=np.float32)       # generous zero border
+    off = 3 * dil + 4
+    xp[:, off:off + H, off:off + W] = x
+    n, by, bx = tiles[:, 0], tiles[:, 1] + off, tiles[:, 2] + off
+    d = [[xp[n, by + a * dil, bx + b * dil] for b in range(4)] for a in range(4)]    # each (T, C)
+    t = [[d[a][0] - d[a][2], d[a][1] + d[a][2], d[a][2] - d[a][1], d[a][1] - d[a][3]] for a in range(4)]
+    V = np.empty((16, T, C), dtype=np.float32)
+    for v in range(4):
+        V[0 * 4 + v] = t[0][v] - t[2][v]
+        V[1 * 4 + v] = t[1][v] + t[2][v]
+        V[2 * 4 + v] = t[2][v] - t[1][v]
+        V[3 * 4 + v] = t[1][v] - t[3][v]
+    M = np.empty((16, T, Cout), dtype=np.float32)
+    for p in range(16):          # GEMM as a 1x1 convolution over a (1, 1, T, C) image
+        M[p] = conv_bn_act_nhwc(V[p][None, None], U[p][:, None, None, :])[0, 0]
+    m = [[M[a * 4 + b] for b in range(4)] for a in range(4)]
+    s = [[(m[0][b] + m[1][b]) + m[2][b] for b in range(4)], [(m[1][b] - m[2][b]) - m[3][b] for b in range(4)]]
+    out = np.zeros((N, H, W, Cout), dtype=np.float32)
+    for a in range(2):
+        yv = [(s[a][0] + s[a][1]) + s[a][2], (s[a][1] - s[a][2]) - s[a][3]]
+        for b in range(2):
+            v = yv[b]
+            if scale is not None:
+                v = (v * np.asarray(scale, dtype=np.float32)).astype(np.float32)
+            if shift is not None:
+                v = (v + np.asarray(shift, dtype=np.float32)).astype(np.float32)
+            if relu:
+                v = np.maximum(v, np.float32(0))
+            yy, xx = tiles[:, 1] + dil + a * dil, tiles[:, 2] + dil + b * dil
+            ok = (yy < H) & (xx < W)
+            out[tiles[ok, 0], yy[ok], xx[ok]] = v[ok]
+    return out

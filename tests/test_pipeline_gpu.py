@@ -273,6 +273,43 @@ def test_model_forward_matches_cpu_within_tolerance():
         assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (k, err, scale)
 
 
+@pytest.mark.parametrize('force', ['direct', 'wino', 'tuned'])
+def test_model_forward_with_hip_convolutions(force):
+    """D4 / D5 inside the model: every conv + BN call site forced onto the implicit-GEMM kernel, onto Winograd
+    where it applies, or left to the tuner -- same tolerance against the host module as the MIOpen path."""
+    import copy
+    from empanada_amd.models import PanopticDeepLab, prepare_for_inference, synthesize_weights, tune_fused_convs
+    from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
+    torch.manual_seed(0)
+    m = synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)).eval()
+    with torch.no_grad():
+        for head in (m.semantic_head, m.ins_center, m.ins_xy):
+            head.head[1].weight.mul_(1e-3)
+    x = torch.randn(2, 1, 128, 128)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = m(x)
+        g = prepare_for_inference(copy.deepcopy(m), 'cuda')
+        sites = [mod for mod in g.modules() if isinstance(mod, FusedConvBNAct)]
+        assert len(sites) > 50
+        if force == 'tuned':
+            rep = tune_fused_convs(g, xd, reps=2)
+            assert len(rep) == len(sites) and all(best in t for best, t in rep.values())
+        else:
+            g(xd)                                        # records the call-site shapes
+            n = 0
+            for mod in sites:
+                if force in mod.candidates(mod._seen[1]):
+                    mod.impl = force
+                    n += 1
+            assert n >= (5 if force == 'wino' else 50)
+        out = g(xd)
+    for k in ref:
+        scale = float(ref[k].abs().max())
+        err = float((out[k].float().cpu() - ref[k]).abs().max())
+        assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (force, k, err, scale)
+
+
 def test_sharded_path_world1_equals_tracker_path():
     """bench.py's path (sharded.py with one rank: tables -> chain -> filters on tables -> fill from the run
     table) paints exactly the volume of track_stack -> filters -> fill_volume_device."""

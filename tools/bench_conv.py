@@ -68,10 +68,28 @@ for name, H, Cin, Cout, k, s, p, d, res in SHAPES:
     def mine():
         return _hip.conv_bn_act_nhwc(x, w_okkc, sc, sh, r, True, s, p, d)
 
+    wino_ms = None
+    if k == 3 and s == 1 and p == d:
+        tiles = torch.from_numpy(_hip.wino_tiles(B, H, H, d)).cuda()
+        U = _hip.wino_filter_transform(w).cuda()
+
+        def wino():
+            return _hip.wino_conv_bn_act(x, U, tiles, d, sc, sh, True)
+
+        wino_ms = timeit(wino)
+        _hip.PROFILE = {}
+        wino()
+        torch.cuda.synchronize()
+        parts = {kk: round(v[0][0].elapsed_time(v[0][1]), 3) for kk, v in _hip.PROFILE.items()}
+        _hip.PROFILE = None
+        werr = (ref() - wino()).abs().max().item()
     a, c, b = timeit(ref), timeit(conv_only), timeit(mine)
     err = (ref() - mine()).abs().max().item()
     fl = 2.0 * y0.numel() * Cin * k * k
     tot_a += a
     tot_b += min(a, b)
     print(f"{name:34s} {a:12.3f} {c:11.3f} {b:12.3f} {fl / b / 1e9:7.1f} {a / b:8.2f}   maxerr {err:.2e}")
+    if wino_ms is not None:
+        print(f"{'   winograd':34s} {wino_ms:12.3f}  speedup vs miopen+bn {a / wino_ms:.2f}  parts {parts}  maxerr {werr:.2e}")
+        tot_b += min(a, b, wino_ms) - min(a, b)
 print(f"sum miopen+bn {tot_a:.2f} ms; sum best-of {tot_b:.2f} ms")
