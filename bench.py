@@ -54,8 +54,9 @@ PMC_TRAFFIC_BYTES_PER_VOXEL = {
 # (profiles/r1_pmc_dense.md)
 PMC_TRAFFIC_RATIO = {'emp_bn_act_nhwc': None, 'emp_dwconv_nhwc': None}
 DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 'emp_conv_bn_act_nhwc',
-                 'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_output_transform')
-MFMA_KERNELS = ('emp_conv_bn_act_nhwc', 'emp_gemm_nt_batched')
+                 'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
+                 'emp_wino_output_transform')
+MFMA_KERNELS = ('emp_conv_bn_act_nhwc', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused')
 MFMA_F32_PEAK_TFLOPS = 157.3                   # dense fp32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -63,7 +64,7 @@ HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--depth', type=int, default=256, help='slices per rank')
     ap.add_argument('--size', type=int, default=512)
@@ -519,7 +520,7 @@ def main():
             'hip_ms_per_pass': per_pass,
             'roofline': roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.cpu_slices > 0:
             log('cpu baseline')
             res['cpu_baseline'] = cpu_baseline(args, vol, heads, args.cpu_slices)
         else:

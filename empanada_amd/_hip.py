@@ -39,6 +39,7 @@ SIGNATURES = {
     'emp_conv_bn_act_nhwc': (_I, [_P, _P, _P, _P, _P, _L, _I] + [_I] * 10 + [_P, _L, _P]),
     'emp_wino_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     'emp_gemm_nt_batched': (_I, [_P, _P, _I, _L, _I, _I, _P, _P]),
+    'emp_wino_gemm_fused': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _I, _P, _P]),
     'emp_wino_output_transform': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
@@ -548,7 +549,7 @@ def wino_filter_transform(w_oihw):
     return torch.stack(U, dim=0).contiguous()
 
 
-def wino_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, out=None):
+def wino_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, out=None, fused=True):
     """3x3 stride-1 convolution with padding == dilation through Winograd F(2x2,3x3) (emp_wino_input_transform,
     emp_gemm_nt_batched, emp_wino_output_transform).  x (N,Cin,H,W) fp32 channels_last; U from
     wino_filter_transform; tiles_dev = torch.from_numpy(wino_tiles(N,H,W,dil)).cuda()."""
@@ -557,7 +558,7 @@ def wino_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, o
     Cout = U.shape[1]
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
     T = tiles_dev.shape[0]
-    V = torch.empty((16, T, Cin), dtype=torch.float32, device=x.device)
+    fused = fused and x.numel() < 2 ** 31
     Mw = torch.empty((16, T, Cout), dtype=torch.float32, device=x.device)
     if out is None:
         out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
@@ -565,10 +566,15 @@ def wino_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, o
     ops = out.stride(3)
     assert out.stride(2) == W * ops and out.stride(0) == H * W * ops, "NHWC channel slice required"
     st = stream()
-    call('emp_wino_input_transform', x.data_ptr(), N, H, W, Cin, dil, _ptr(tiles_dev), T, _ptr(V), st,
-         alg_bytes=4 * (x.numel() + V.numel()))
-    call('emp_gemm_nt_batched', _ptr(V), _ptr(U), 16, T, Cout, Cin, _ptr(Mw), st,
-         alg_bytes=4 * (V.numel() + U.numel() + Mw.numel()), alg_flops=2 * 16 * T * Cout * Cin)
+    if fused:       # input transform inside the GEMM's loader: V never exists in memory
+        call('emp_wino_gemm_fused', x.data_ptr(), N, H, W, Cin, dil, _ptr(tiles_dev), T, _ptr(U), Cout, _ptr(Mw), st,
+             alg_bytes=4 * (x.numel() + U.numel() + Mw.numel()), alg_flops=2 * 16 * T * Cout * Cin)
+    else:
+        V = torch.empty((16, T, Cin), dtype=torch.float32, device=x.device)
+        call('emp_wino_input_transform', x.data_ptr(), N, H, W, Cin, dil, _ptr(tiles_dev), T, _ptr(V), st,
+             alg_bytes=4 * (x.numel() + V.numel()))
+        call('emp_gemm_nt_batched', _ptr(V), _ptr(U), 16, T, Cout, Cin, _ptr(Mw), st,
+             alg_bytes=4 * (V.numel() + U.numel() + Mw.numel()), alg_flops=2 * 16 * T * Cout * Cin)
     call('emp_wino_output_transform', _ptr(Mw), _ptr(tiles_dev), T, N, H, W, Cout, dil, _ptr(scale), _ptr(shift),
          int(bool(relu)), out.data_ptr(), ops, st, alg_bytes=4 * (Mw.numel() + N * Cout * H * W))
     return out

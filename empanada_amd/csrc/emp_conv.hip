@@ -31,10 +31,16 @@ struct ConvGeom {
     int64_t M, out_ps, res_ps;
     int tiles_m, tiles_n;
     int64_t x_bs, w_bs, out_bs;      // blockIdx.y batches (Winograd positions): element strides of x, w, out
+    const int32_t *tiles;            // MODE 1: (M, 3) Winograd tile table
 };
 
 // NT = 32-wide cout tiles per wave: block tile 128 x (64 * NT) (NT = 1 for layers with Cout <= 64)
-template <int NT>
+// MODE 0: A rows are output pixels of a convolution (implicit GEMM over filter taps).
+// MODE 1: A rows are Winograd tiles and blockIdx.y is the position p = 4u + v; the loader fetches the four patch
+//         pixels position p combines and applies the input transform on the way into LDS, so V never exists in
+//         memory:  V_p = op_u(op_v(d[a0][b0], d[a0][b1]), op_v(d[a1][b0], d[a1][b1])), same roundings as
+//         wino_input_kernel.
+template <int NT, int MODE>
 __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom g)
 {
     constexpr int BN = 64 * NT;
@@ -60,21 +66,49 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
     const int tid = threadIdx.x;
     const int lrow = tid >> 3, lcol = (tid & 7) * 4;
 
-    // the 4 A rows (output pixels) and BROWS B rows (couts) this thread stages, fixed over the K loop
+    // the 4 A rows (output pixels / Winograd tiles) and BROWS B rows (couts) this thread stages, fixed over the K loop
     int a_n[4], a_iy[4], a_ix[4];
     bool a_ok[4], b_ok[BROWS];
     const float *b_ptr[BROWS];
     const int taps = g.KH * g.KW;
+    int w_off[4][4];                   // MODE 1: element offsets of the 4 patch pixels of each row (0 when masked)
+    unsigned w_mask[4];                // MODE 1: bit k set = pixel k inside the image
+    float w_su = 1.f, w_sv = 1.f;      // MODE 1: sign of the second operand of the row / column combination
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t p = m0 + lrow + 32 * i;
-        a_ok[i] = p < g.M;
-        const int64_t pp = a_ok[i] ? p : 0;
-        const int ox = (int)(pp % g.OW);
-        const int oy = (int)((pp / g.OW) % g.OH);
-        a_n[i] = (int)(pp / ((int64_t)g.OW * g.OH));
-        a_iy[i] = oy * g.stride - g.pad;
-        a_ix[i] = ox * g.stride - g.pad;
+        for (int i = 0; i < 4; ++i) {
+            const int64_t p = m0 + lrow + 32 * i;
+            a_ok[i] = p < g.M;
+            const int64_t pp = a_ok[i] ? p : 0;
+            const int ox = (int)(pp % g.OW);
+            const int oy = (int)((pp / g.OW) % g.OH);
+            a_n[i] = (int)(pp / ((int64_t)g.OW * g.OH));
+            a_iy[i] = oy * g.stride - g.pad;
+            a_ix[i] = ox * g.stride - g.pad;
+        }
+    } else {
+        // B^T rows: u = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+        const int u = blockIdx.y >> 2, v = blockIdx.y & 3;
+        const int af = (u == 0) ? 0 : (u == 2) ? 2 : 1, as2 = (u == 0) ? 2 : (u == 1) ? 2 : (u == 2) ? 1 : 3;
+        const int bf = (v == 0) ? 0 : (v == 2) ? 2 : 1, bs2 = (v == 0) ? 2 : (v == 1) ? 2 : (v == 2) ? 1 : 3;
+        w_su = (u == 1) ? 1.f : -1.f;
+        w_sv = (v == 1) ? 1.f : -1.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t t = m0 + lrow + 32 * i;
+            const bool ok = t < g.M;
+            const int64_t tt = ok ? t : 0;
+            const int n = g.tiles[3 * tt], by = g.tiles[3 * tt + 1], bx = g.tiles[3 * tt + 2];
+            w_mask[i] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = by + ((k >> 1) ? as2 : af) * g.dil, xx = bx + ((k & 1) ? bs2 : bf) * g.dil;
+                const bool in = ok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                w_off[i][k] = in ? (((n * g.H + yy) * g.W + xx) * g.Cin + lcol) : lcol;
+                w_mask[i] |= in ? (1u << k) : 0u;
+            }
+            a_ok[i] = ok;
+        }
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
@@ -97,7 +131,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
 
     const int cslabs = g.Cin / CG_BK;
     const int S = taps * cslabs;
-    float4 ra[4], rb[BROWS];
+    float4 ra[MODE == 0 ? 4 : 16], rb[BROWS];
 
     // Staging state of the NEXT slab to load: filter tap, channel offset, and per A row the source pointer of the
     // tap (rows whose tap falls outside the image, or past M, read a dummy address and are zeroed after the load:
@@ -114,17 +148,25 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
             a_ptr[i] = a_in[i] ? g.x + (((int64_t)a_n[i] * g.H + iy) * g.W + ix) * g.Cin + lcol : g.x + lcol;
         }
     };
-    set_tap(0);
+    if constexpr (MODE == 0) set_tap(0);
     auto load_slab = [&]() {
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_ptr[i] + ld_c0);
+            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_ptr[i] + ld_c0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ra[i * 4 + k] = *reinterpret_cast<const float4 *>(g.x + w_off[i][k] + ld_c0);
+        }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const float4 *>(b_ptr[i] + (int64_t)ld_tap * g.Cin + ld_c0);
         ld_c0 += CG_BK;
         if (ld_c0 == g.Cin) {               // block-uniform
             ld_c0 = 0;
             ++ld_tap;
-            if (ld_tap < taps) set_tap(ld_tap);
+            if constexpr (MODE == 0)
+                if (ld_tap < taps) set_tap(ld_tap);
         }
     };
     // a_in of the slab held in ra: captured before load_slab advances the tap
@@ -132,8 +174,24 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
     auto store_slab = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float4 v = ra[i];
-            if (!r_in[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v;
+            if constexpr (MODE == 0) {
+                v = ra[i];
+                if (!r_in[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                float4 d[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    d[k] = ra[i * 4 + k];
+                    if (!((w_mask[i] >> k) & 1u)) d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#define CG_COMB(p, q, sg) make_float4(__fadd_rn(p.x, __fmul_rn(sg, q.x)), __fadd_rn(p.y, __fmul_rn(sg, q.y)), \
+                                      __fadd_rn(p.z, __fmul_rn(sg, q.z)), __fadd_rn(p.w, __fmul_rn(sg, q.w)))
+                const float4 c0 = CG_COMB(d[0], d[1], w_sv);      // along columns, patch row a0
+                const float4 c1 = CG_COMB(d[2], d[3], w_sv);      // patch row a1
+                v = CG_COMB(c0, c1, w_su);                        // along rows
+#undef CG_COMB
+            }
             *reinterpret_cast<float4 *>(&As[buf * CG_BM * CG_LD + (lrow + 32 * i) * CG_LD + lcol]) = v;
         }
 #pragma unroll
@@ -145,7 +203,9 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
     };
 #define CG_LOAD_NEXT()                                   \
     do {                                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) r_in[i_] = a_in[i_]; \
+        if constexpr (MODE == 0) {                       \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) r_in[i_] = a_in[i_]; \
+        }                                                \
         load_slab();                                     \
     } while (0)
 
@@ -285,7 +345,7 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KH = KH; g.KW = KW;
     g.stride = stride; g.pad = pad; g.dil = dil; g.relu = relu;
     g.M = (int64_t)N * OH * OW; g.out_ps = out_pixel_stride; g.res_ps = res_pixel_stride;
-    g.x_bs = g.w_bs = g.out_bs = 0;
+    g.x_bs = g.w_bs = g.out_bs = 0; g.tiles = nullptr;
     const int64_t tiles_m = emp_cdiv(g.M, CG_BM);
     const bool narrow = Cout <= 64 || (Cout % 128 != 0 && Cout % 128 <= 64 && Cout < 512);
     g.tiles_n = (int)emp_cdiv(Cout, narrow ? 64 : 128);
@@ -293,8 +353,8 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     g.tiles_m = (int)tiles_m;
     const int T = g.tiles_m * g.tiles_n;
     const int grid = 8 * ((T + 7) / 8);
-    if (narrow) hipLaunchKernelGGL((conv_igemm_f32_kernel<1>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
-    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+    if (narrow) hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
     EMP_CHECK_LAUNCH("emp_conv_bn_act_nhwc");
     return EMP_OK;
 }
@@ -423,15 +483,41 @@ extern "C" int emp_gemm_nt_batched(const float *A, const float *B, int batch, in
     g.N = 1; g.H = 1; g.W = (int)M; g.Cin = K; g.OH = 1; g.OW = (int)M; g.Cout = N; g.KH = g.KW = 1;
     g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
     g.M = M; g.out_ps = N; g.res_ps = N;
-    g.x_bs = M * K; g.w_bs = (int64_t)N * K; g.out_bs = M * N;
+    g.x_bs = M * K; g.w_bs = (int64_t)N * K; g.out_bs = M * N; g.tiles = nullptr;
     const bool narrow = N <= 64;
     g.tiles_m = (int)emp_cdiv(M, CG_BM);
     g.tiles_n = (int)emp_cdiv(N, narrow ? 64 : 128);
     const int T = g.tiles_m * g.tiles_n;
     dim3 grid(8 * ((T + 7) / 8), batch);
-    if (narrow) hipLaunchKernelGGL((conv_igemm_f32_kernel<1>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
-    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+    if (narrow) hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
     EMP_CHECK_LAUNCH("emp_gemm_nt_batched");
+    return EMP_OK;
+}
+
+extern "C" int emp_wino_gemm_fused(const float *x, int N, int H, int W, int Cin, int dil, const int32_t *tiles,
+                                   int64_t T, const float *U, int Cout, float *Mw, void *stream)
+{
+    EMP_REQUIRE(x && tiles && U && Mw, "wino_gemm: null pointer");
+    EMP_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % CG_BK == 0 && Cout > 0 && dil >= 1 && T >= 0,
+                "wino_gemm: bad shape (Cin must be a multiple of %d)", CG_BK);
+    EMP_REQUIRE((int64_t)N * H * W * Cin < (1LL << 31) && T < (1LL << 31), "wino_gemm: activation too large for 32-bit offsets");
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(U)) & 15) == 0, "wino_gemm: alignment");
+    if (T == 0) return EMP_OK;
+    ConvGeom g;
+    g.x = x; g.w = U; g.scale = g.shift = g.res = nullptr; g.out = Mw;
+    g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.OH = 1; g.OW = 1; g.Cout = Cout; g.KH = g.KW = 1;
+    g.stride = 1; g.pad = 0; g.dil = dil; g.relu = 0;
+    g.M = T; g.out_ps = Cout; g.res_ps = Cout;
+    g.x_bs = 0; g.w_bs = (int64_t)Cout * Cin; g.out_bs = T * Cout; g.tiles = tiles;
+    const bool narrow = Cout <= 64;
+    g.tiles_m = (int)emp_cdiv(T, CG_BM);
+    g.tiles_n = (int)emp_cdiv(Cout, narrow ? 64 : 128);
+    const int nt = g.tiles_m * g.tiles_n;
+    dim3 grid(8 * ((nt + 7) / 8), 16);
+    if (narrow) hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 1>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 1>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+    EMP_CHECK_LAUNCH("emp_wino_gemm_fused");
     return EMP_OK;
 }
 

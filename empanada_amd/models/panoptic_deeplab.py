@@ -113,7 +113,10 @@ class FusedConvBNAct(nn.Module):
     """Conv2d + FusedBNAct (+ residual) as one call with three interchangeable implementations:
       'miopen' : MIOpen convolution, then the emp_bn_act_nhwc epilogue pass              (default)
       'direct' : emp_conv_bn_act_nhwc -- implicit GEMM on the fp32 matrix cores, epilogue fused
-      'wino'   : Winograd F(2x2,3x3) -- emp_wino_input_transform / emp_gemm_nt_batched / emp_wino_output_transform
+      'wino'   : Winograd F(2x2,3x3), input transform inside the GEMM loader -- emp_wino_gemm_fused /
+                 emp_wino_output_transform
+      'wino_sep': the same with V materialised -- emp_wino_input_transform / emp_gemm_nt_batched /
+                 emp_wino_output_transform (less L2 traffic per matrix-core FLOP; wins when Cin is large)
     tune_fused_convs() times the candidates on the layer's real shape and keeps the fastest."""
 
     def __init__(self, conv, bn):
@@ -136,20 +139,20 @@ class FusedConvBNAct(nn.Module):
             out.append('direct')
             if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == c.dilation and c.out_channels % 4 == 0
                     and not has_residual):
-                out.append('wino')
+                out.extend(['wino', 'wino_sep'])
         return out
 
     def _prepare(self, impl):
         from .. import _hip
         if impl == 'direct' and self._w_okkc is None:
             self._w_okkc = self.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
-        if impl == 'wino' and self._U is None:
+        if impl in ('wino', 'wino_sep') and self._U is None:
             self._U = _hip.wino_filter_transform(self.conv.weight.detach())
 
     def release(self, keep):
         if keep != 'direct':
             self._w_okkc = None
-        if keep != 'wino':
+        if keep not in ('wino', 'wino_sep'):
             self._U = None
             self._tiles = {}
 
@@ -173,7 +176,7 @@ class FusedConvBNAct(nn.Module):
         if key not in self._tiles:
             self._tiles[key] = torch.from_numpy(_hip.wino_tiles(key[0], key[1], key[2], c.dilation[0])).to(x.device)
         return _hip.wino_conv_bn_act(x, self._U, self._tiles[key], c.dilation[0], self.bn.scale, self.bn.shift,
-                                     self.bn.relu, out)
+                                     self.bn.relu, out, fused=(impl == 'wino'))
 
 
 def _up_bilinear(x, size, hip_ops, out=None):

@@ -118,6 +118,11 @@ int emp_wino_input_transform(const float *x, int N, int H, int W, int C, int dil
                              int64_t T, float *V, void *stream);
 int emp_gemm_nt_batched(const float *A, const float *B, int batch, int64_t M, int N, int K, float *C,
                         void *stream);
+/* Steps 1 + 2 in one launch: the GEMM's loader fetches, per tile and position, the four patch pixels B^T d B
+ * combines and applies the transform on the way into LDS (same roundings as emp_wino_input_transform), so V is
+ * never written.  Mw (16, T, Cout).  N*H*W*Cin < 2^31.                                                       */
+int emp_wino_gemm_fused(const float *x, int N, int H, int W, int Cin, int dil, const int32_t *tiles,
+                        int64_t T, const float *U, int Cout, float *Mw, void *stream);
 int emp_wino_output_transform(const float *Mw, const int32_t *tiles, int64_t T, int N, int H, int W,
                               int Cout, int dil, const float *scale, const float *shift, int relu,
                               float *out, int64_t out_pixel_stride, void *stream);

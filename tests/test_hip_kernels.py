@@ -541,6 +541,9 @@ def test_winograd_conv(hip, cfg):
     np.testing.assert_array_equal(U.numpy().view(np.uint32), OD.wino_filter_transform(w.numpy()).view(np.uint32))
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     got = hip.wino_conv_bn_act(xd, U.cuda(), torch.from_numpy(tiles).cuda(), dil, sc.cuda(), sh.cuda(), True)
+    unfused = hip.wino_conv_bn_act(xd, U.cuda(), torch.from_numpy(tiles).cuda(), dil, sc.cuda(), sh.cuda(), True,
+                                   fused=False)
+    assert torch.equal(got, unfused)           # loader-fused input transform == separate transform kernel
     exp = OD.wino_conv_bn_act(x.permute(0, 2, 3, 1).numpy(), w.numpy(), tiles, dil, sc.numpy(), sh.numpy(), True)
     np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
     ref = torch.relu(torch.nn.functional.conv2d(x, w, None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1)
