@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['emp_pixel.hip', 'emp_runs.hip', 'emp_ranges.hip', 'emp_dense.hip', 'emp_conv.hip']
+SOURCES = ['emp_pixel.hip', 'emp_runs.hip', 'emp_ranges.hip', 'emp_dense.hip', 'emp_conv.hip', 'emp_chain.cpp']
 LIB = os.path.join(HERE, 'libemp_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17', '-Wno-unused-value',
          '-Wno-unused-result']
@@ -28,7 +28,7 @@ def build(force=False, verbose=True):
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace('.hip', '.o'))
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
         if force or _stale(o, [s] + headers):
             cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
             if verbose:

@@ -13,6 +13,8 @@ kernel groups and runs the label-propagation chain (forward + backward matching)
 tables; the result is identical to forward_matching + backward_matching + update_trackers on the same
 slices (tests/test_pipeline_gpu.py).
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -361,9 +363,36 @@ def tables_from_stack(pan, labels, thing_list, label_divisor):
     return table, host
 
 
-def chain_from_tables(host, D, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25):
+_LSAP_FN = ctypes.CFUNCTYPE(ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.c_int64, ctypes.c_int64,
+                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64))
+
+
+def _lsap_callback(iou_ptr, n_rows, n_cols, rows_out, cols_out):
+    """scipy's Hungarian step for emp_chain_class (the routine the reference calls, matcher.py:213)"""
+    try:
+        iou = np.ctypeslib.as_array(iou_ptr, shape=(n_rows, n_cols))
+        rows, cols = linear_sum_assignment(iou, maximize=True)
+        for i in range(len(rows)):
+            rows_out[i] = int(rows[i])
+            cols_out[i] = int(cols[i])
+        return len(rows)
+    except Exception:                        # never unwind through the C frame
+        return -1
+
+
+_LSAP_C = _LSAP_FN(_lsap_callback)
+
+
+def _i64p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def chain_from_tables(host, D, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25,
+                      native=True):
     """Host half of track_stack: forward + backward label propagation over the component tables of D slices.
-    Returns (comp_final (n,) final label per component, first_seen {class: {label: order of first update}})."""
+    Returns (comp_final (n,) final label per component, first_seen {class: {label: order of first update}}).
+    native=True runs the loop in C++ (emp_chain_class); native=False is the numpy statement of the same rules
+    (_ClassChain), kept as the executable specification the tests compare the native loop with."""
     c_slice, c_label, c_area, c_cls, trip = (host[k] for k in ('c_slice', 'c_label', 'c_area', 'c_cls', 'trip'))
     nc = len(c_slice)
     comp_final = np.zeros(nc, dtype=np.int64)
@@ -375,11 +404,8 @@ def chain_from_tables(host, D, labels, thing_list, label_divisor, merge_iou_thr=
         bounds = np.searchsorted(c_slice[sel], np.arange(D + 1))
         pos = np.zeros(max(nc, 1), dtype=np.int64)
         pos[sel] = np.arange(len(sel)) - bounds[c_slice[sel]]
-        slices = []
-        for t in range(D):
-            cs = sel[bounds[t]:bounds[t + 1]]
-            slices.append(_Inst(c_label[cs], cs, np.arange(len(cs), dtype=np.int64), c_area[cs]))
-        if l in thing_list:
+        is_thing = l in thing_list
+        if is_thing:
             # overlap triplets of this class, grouped by the slice of the first component
             ta, tb, tv = trip[:, 0], trip[:, 1], trip[:, 2]
             m = c_cls[ta] == l if len(ta) else np.zeros(0, dtype=bool)
@@ -388,7 +414,32 @@ def chain_from_tables(host, D, labels, thing_list, label_divisor, merge_iou_thr=
             ta, tb, tv = ta[o], tb[o], tv[o]
             tb_bounds = np.searchsorted(c_slice[ta], np.arange(D + 1)) if len(ta) else np.zeros(D + 1, np.int64)
             pa, pb = pos[ta], pos[tb]
-
+        else:
+            tb_bounds = np.zeros(D + 1, np.int64)
+            pa = pb = tv = np.zeros(0, np.int64)
+        if native:
+            arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in
+                    (bounds, c_label[sel], c_area[sel], tb_bounds, pa, pb, tv)]
+            out = np.zeros(max(len(sel), 1), dtype=np.int64)
+            seen = np.zeros(max(len(sel), 1), dtype=np.int64)
+            n_seen = ctypes.c_int64(0)
+            rc = _hip.load().emp_chain_class(D, _i64p(arrs[0]), _i64p(arrs[1]), _i64p(arrs[2]), int(is_thing),
+                                             _i64p(arrs[3]), _i64p(arrs[4]), _i64p(arrs[5]), _i64p(arrs[6]), int(l),
+                                             int(label_divisor), float(merge_iou_thr), float(merge_ioa_thr),
+                                             ctypes.cast(_LSAP_C, ctypes.c_void_p), _i64p(out), _i64p(seen),
+                                             ctypes.byref(n_seen))
+            if rc == 1:
+                raise ValueError("attempt to get argmax of an empty sequence")
+            if rc != 0:
+                raise RuntimeError(f"emp_chain_class failed ({rc})")
+            comp_final[sel] = out[:len(sel)]
+            first_seen[l] = {int(lab): i for i, lab in enumerate(seen[:n_seen.value].tolist())}
+            continue
+        slices = []
+        for t in range(D):
+            cs = sel[bounds[t]:bounds[t + 1]]
+            slices.append(_Inst(c_label[cs], cs, np.arange(len(cs), dtype=np.int64), c_area[cs]))
+        if is_thing:
             def pair_matrix(t, bounds=bounds, tb_bounds=tb_bounds, pa=pa, pb=pb, tv=tv):
                 n0, n1 = bounds[t + 1] - bounds[t], bounds[t + 2] - bounds[t + 1]
                 M = np.zeros((n0, n1), dtype=np.int64)

@@ -329,6 +329,27 @@ int emp_scatter_yz_u32(uint32_t *vol, int Z, int Y, int X, const int32_t *r_star
                        const int32_t *r_comp, const int32_t *c_slice, const uint32_t *value,
                        int64_t n_runs, void *stream);
 
+/* ---- M4/M5 (host): slice-to-slice label propagation over component tables, plain C++ on the CPU ---------
+ * replaces RLEMatcher.__call__ driven by forward_matching / backward_matching
+ *          empanada/inference/matcher.py:262-323, inference/patterns.py:60-121
+ * for the whole-stack path, where the GPU has already reduced every slice to connected components
+ * (emp_runs_label) and their overlaps with the next slice (emp_runs_overlap_next).  One call per class.
+ * Components sorted by (slice, cc label): slice t owns [bounds[t], bounds[t+1]); pa / pb are positions inside
+ * slice t / t+1 of the overlap triplets [tb_bounds[t], tb_bounds[t+1]).  IoU fp64, IoA fp32, thresholds and merge
+ * rule as in the reference; the Hungarian step runs only when an overlap matrix has a row or column with two
+ * non-zeros and is delegated to `lsap` (the caller passes scipy.optimize.linear_sum_assignment(maximize=True),
+ * the routine the reference calls, so ties break identically): lsap(iou row-major, n_rows, n_cols, rows_out,
+ * cols_out) -> number of pairs or -1.
+ * comp_final[n]: final label per component (sorted order); seen_labels / n_seen: labels in order of first update
+ * when slices are visited last to first (the tracker's dict order).
+ * Returns 0; 1 where the reference raises ValueError (ioa_thr <= 0 and an empty target slice); 2 lsap failed.  */
+typedef int64_t (*emp_lsap_fn)(const double *iou, int64_t n_rows, int64_t n_cols, int64_t *rows_out,
+                               int64_t *cols_out);
+int emp_chain_class(int64_t D, const int64_t *bounds, const int64_t *comp_label, const int64_t *comp_area,
+                    int is_thing, const int64_t *tb_bounds, const int64_t *pa, const int64_t *pb,
+                    const int64_t *tv, int64_t class_id, int64_t label_divisor, double iou_thr, double ioa_thr,
+                    emp_lsap_fn lsap, int64_t *comp_final, int64_t *seen_labels, int64_t *n_seen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,3 +251,49 @@ def test_two_rank_plane_trackers_equal_single_rank(axis_name):
             assert tuple(a['box']) == tuple(g[k][0])
             np.testing.assert_array_equal(a['starts'], g[k][1])
             np.testing.assert_array_equal(a['runs'], g[k][2])
+
+
+def _blobby_stack(seed, shape=(40, 48, 56), n=60):
+    """random boxes that move, split and merge from slice to slice: overlap matrices with several non-zeros per
+    row / column, so the Hungarian callback and the IoA merge rule are exercised"""
+    rng = np.random.default_rng(seed)
+    D, H, W = shape
+    pan = np.zeros(shape, dtype=np.int64)
+    for _ in range(n):
+        z0, z1 = sorted(rng.integers(0, D, 2))
+        y, x = rng.integers(0, H - 8), rng.integers(0, W - 8)
+        h, w = rng.integers(3, 12), rng.integers(3, 12)
+        cls = 1 if rng.random() < 0.8 else 2
+        for z in range(z0, z1 + 1):
+            y = int(np.clip(y + rng.integers(-2, 3), 0, H - h))
+            x = int(np.clip(x + rng.integers(-2, 3), 0, W - w))
+            pan[z, y:y + h, x:x + w] = cls * DIV + 1 + rng.integers(0, 3)
+            if rng.random() < 0.2:
+                pan[z, y + h // 2, x:x + w] = 0                     # split
+    return pan
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+@pytest.mark.parametrize('thr', [(0.25, 0.25), (0.5, 0.1), (0.1, 0.6)])
+def test_native_chain_equals_numpy_chain(seed, thr):
+    """emp_chain_class (C++) against the numpy statement of the same rules (_ClassChain), incl. the order in which
+    labels are first updated"""
+    pan = _blobby_stack(seed)
+    host, _ = cpu_tables(pan, [1, 2], [1])
+    a, fa = chain_from_tables(host, pan.shape[0], [1, 2], [1], DIV, thr[0], thr[1], native=True)
+    b, fb = chain_from_tables(host, pan.shape[0], [1, 2], [1], DIV, thr[0], thr[1], native=False)
+    np.testing.assert_array_equal(a, b)
+    assert {k: list(v.items()) for k, v in fa.items()} == {k: list(v.items()) for k, v in fb.items()}
+    assert len(np.unique(a)) > 5
+
+
+def test_native_chain_error_and_empty_cases():
+    host, _ = cpu_tables(np.zeros((5, 8, 8), dtype=np.int64), [1], [1])
+    a, fa = chain_from_tables(host, 5, [1], [1], DIV, 0.25, 0.25)
+    assert len(a) == 0 and fa == {1: {}}
+    pan = np.zeros((3, 8, 8), dtype=np.int64)
+    pan[1, 2:5, 2:5] = DIV + 1                                       # empty target slice, then an object
+    host, _ = cpu_tables(pan, [1], [1])
+    for native in (True, False):
+        with pytest.raises(ValueError):
+            chain_from_tables(host, 3, [1], [1], DIV, 0.25, 0.0, native=native)
