@@ -70,6 +70,8 @@ def parse():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--batch', type=int, default=32, help='slices per model call')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
+    ap.add_argument('--save-tune', default=None, help='write the tuned conv implementation per call site (json)')
+    ap.add_argument('--load-tune', default=None, help='replay conv implementations from a --save-tune file')
     ap.add_argument('--no-tune', action='store_true', help='keep MIOpen + epilogue pass for every convolution')
     ap.add_argument('--cpu-slices', type=int, default=96, help='slices of the same workload for the CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -110,19 +112,32 @@ class Pipeline:
         self.post_stream = torch.cuda.Stream(device=device)
 
     @torch.no_grad()
-    def tune(self, size):
-        """warm-up only: let every conv + BN call site pick its fastest implementation on the bench shapes"""
+    def tune(self, size, save=None, load=None):
+        """warm-up only: let every conv + BN call site pick its fastest implementation on the bench shapes
+        (or replay the choices of an earlier run: profiler passes distort the timings the tuner relies on)"""
         from empanada_amd.models import tune_fused_convs
+        from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
         if self.dtype != torch.float32:
+            return
+        counts = {}
+        if load:
+            choice = json.load(open(load))
+            for name, m in self.model.named_modules():
+                if isinstance(m, FusedConvBNAct):
+                    m.impl = choice.get(name, 'miopen')
+                    counts[m.impl] = counts.get(m.impl, 0) + 1
+            self.tuned = counts
+            log(f'conv call sites loaded from {load}: {counts}')
             return
         x = torch.rand((self.batch, 1, size, size), device=self.device).contiguous(memory_format=torch.channels_last)
         rep = tune_fused_convs(self.model, x)
-        counts = {}
         for _, (best, _) in rep.items():
             counts[best] = counts.get(best, 0) + 1
         self.tuned = counts
         saved = sum(t['miopen'] - min(t.values()) for _, t in rep.values())
         log(f'conv call sites tuned: {counts}; isolated saving {saved:.2f} ms per batch of {self.batch}')
+        if save:
+            json.dump({k: v[0] for k, v in rep.items()}, open(save, 'w'), indent=1)
 
     @torch.no_grad()
     def forward(self, vol):
@@ -246,7 +261,7 @@ def main_orthoplane(args, device, rank, world):
     log(f'inputs ready ({n_obj} planted objects)')
     pipe = Pipeline(args, device)
     if not args.no_tune:
-        pipe.tune(S)
+        pipe.tune(S, args.save_tune, args.load_tune)
     shape3d = (S, S, S)
     host_out = torch.empty(shape3d, dtype=torch.int32).pin_memory() if rank == 0 else None
 
@@ -376,7 +391,7 @@ def main():
     log(f'inputs ready ({n_obj} planted objects); building model')
     pipe = Pipeline(args, device)
     if not args.no_tune:
-        pipe.tune(S)
+        pipe.tune(S, args.save_tune, args.load_tune)
     host_out = torch.empty((D, S, S), dtype=torch.int32).pin_memory()
     shape3d = (D, S, S)
 
