@@ -40,7 +40,9 @@ struct ConvGeom {
 //         pixels position p combines and applies the input transform on the way into LDS, so V never exists in
 //         memory:  V_p = op_u(op_v(d[a0][b0], d[a0][b1]), op_v(d[a1][b0], d[a1][b1])), same roundings as
 //         wino_input_kernel.
-template <int NT, int MODE>
+// RESPF: the residual values of the thread's epilogue rows are requested before the K loop (registers), so their
+//        HBM latency hides behind the matrix work instead of sitting in the epilogue (short-K 1x1 convs).
+template <int NT, int MODE, bool RESPF = false>
 __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom g)
 {
     constexpr int BN = 64 * NT;
@@ -209,6 +211,21 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
         load_slab();                                     \
     } while (0)
 
+    constexpr int C4 = BN / 4;                         // float4 columns of the output tile
+    constexpr int RPI = CG_THREADS / C4;               // epilogue rows per iteration
+    constexpr int NRE = CG_BM / RPI;                   // epilogue iterations per thread
+    const int ccol = (tid % C4) * 4, crow = tid / C4;
+    const int co = n0 + ccol;
+    float4 rpre[RESPF ? NRE : 1];
+    if constexpr (RESPF) {
+#pragma unroll
+        for (int it = 0; it < NRE; ++it) {
+            const int64_t p = m0 + crow + it * RPI;
+            rpre[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < g.M && co + 3 < g.Cout) rpre[it] = *reinterpret_cast<const float4 *>(g.res + p * g.res_ps + co);
+        }
+    }
+
     // Pipeline: slab s is consumed from LDS buffer s & 1 while slab s+1 (already in registers, loaded one
     // iteration earlier) is written to the other buffer between the MFMAs, and the global loads of slab s+2 are
     // issued right behind it: a load has a whole iteration (64 MFMAs per wave) to land, and the LDS writes, address
@@ -273,10 +290,6 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
                 Cs[row * CLD + wn * 32 * NT + j * 32 + r] = acc[i][j][q];
             }
     __syncthreads();
-    constexpr int C4 = BN / 4;                         // float4 columns of the tile
-    constexpr int RPI = CG_THREADS / C4;               // rows per iteration
-    const int ccol = (tid % C4) * 4, crow = tid / C4;
-    const int co = n0 + ccol;
     const bool vec_ok = (co + 3 < g.Cout) && ((g.out_ps & 3) == 0) && ((g.res_ps & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) &&
                         (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 15) == 0) && ((g.Cout & 3) == 0);
@@ -287,36 +300,40 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
             if (g.scale) sc[e] = g.scale[co + e];
             if (g.shift) sh[e] = g.shift[co + e];
         }
-#pragma unroll 4
-    for (int row = crow; row < CG_BM; row += RPI) {
+#pragma unroll
+    for (int it = 0; it < NRE; ++it) {
+        const int row = crow + it * RPI;
         const int64_t p = m0 + row;
-        if (p >= g.M) break;
-        const float4 a4 = *reinterpret_cast<const float4 *>(&Cs[row * CLD + ccol]);
-        float v[4] = {a4.x, a4.y, a4.z, a4.w};
-        float rr[4] = {0.f, 0.f, 0.f, 0.f};
-        if (g.res) {
+        if (p < g.M) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(&Cs[row * CLD + ccol]);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            float rr[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (RESPF) {
+                rr[0] = rpre[it].x; rr[1] = rpre[it].y; rr[2] = rpre[it].z; rr[3] = rpre[it].w;
+            } else if (g.res) {
+                if (vec_ok) {
+                    const float4 r4 = *reinterpret_cast<const float4 *>(g.res + p * g.res_ps + co);
+                    rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < g.Cout) rr[e] = g.res[p * g.res_ps + co + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (g.scale) v[e] = __fmul_rn(v[e], sc[e]);
+                if (g.shift) v[e] = __fadd_rn(v[e], sh[e]);
+                if (g.res) v[e] = __fadd_rn(v[e], rr[e]);
+                if (g.relu) v[e] = fmaxf(v[e], 0.f);
+            }
             if (vec_ok) {
-                const float4 r4 = *reinterpret_cast<const float4 *>(g.res + p * g.res_ps + co);
-                rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w;
+                *reinterpret_cast<float4 *>(g.out + p * g.out_ps + co) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (co + e < g.Cout) rr[e] = g.res[p * g.res_ps + co + e];
+                    if (co + e < g.Cout) g.out[p * g.out_ps + co + e] = v[e];
             }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (g.scale) v[e] = __fmul_rn(v[e], sc[e]);
-            if (g.shift) v[e] = __fadd_rn(v[e], sh[e]);
-            if (g.res) v[e] = __fadd_rn(v[e], rr[e]);
-            if (g.relu) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (vec_ok) {
-            *reinterpret_cast<float4 *>(g.out + p * g.out_ps + co) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (co + e < g.Cout) g.out[p * g.out_ps + co + e] = v[e];
         }
     }
 }
@@ -353,8 +370,16 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     g.tiles_m = (int)tiles_m;
     const int T = g.tiles_m * g.tiles_n;
     const int grid = 8 * ((T + 7) / 8);
-    if (narrow) hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
-    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+    // residual prefetch: needs the vector path for every thread of every tile
+    const bool respf = residual && Cout % (narrow ? 64 : 128) == 0 && (res_pixel_stride & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
+    if (narrow) {
+        if (respf) hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0, true>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+        else hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+    } else {
+        if (respf) hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, true>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+        else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+    }
     EMP_CHECK_LAUNCH("emp_conv_bn_act_nhwc");
     return EMP_OK;
 }
