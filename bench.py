@@ -89,7 +89,8 @@ def parse():
 def build_inputs(D, S, device, seed_offset=0):
     from empanada_amd import synthetic as SY
     shape = (D, S, S)
-    vol = torch.from_numpy(SY.em_volume(shape, seed=1234 + seed_offset)).to(device)
+    from empanada_amd.data import DeviceVolume
+    vol = DeviceVolume(SY.em_volume(shape, seed=1234 + seed_offset), NORM['mean'], NORM['std'], 16, device)
     lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321 + seed_offset)
     heads = {'sem': [], 'ctr_hmp': [], 'offsets': []}
     for s in range(0, D, 64):                    # chunked to bound the generator's temporaries
@@ -144,18 +145,19 @@ class Pipeline:
             json.dump({k: v[0] for k, v in rep.items()}, open(save, 'w'), indent=1)
 
     @torch.no_grad()
-    def forward(self, vol):
-        """uint8 (D,H,W) resident volume -> resident sem probabilities (D,1,H,W) fp32 + a checksum of all heads"""
-        D, H, W = vol.shape
-        prob = torch.empty((D, 1, H, W), dtype=torch.float32, device=self.device)
+    def forward(self, dv, axis='xy', lo=0, hi=None):
+        """slices [lo, hi) of one plane of the resident uint8 volume (empanada_amd.data.DeviceVolume: strided
+        gather + normalise + pad in one HIP pass) -> resident sem probabilities (n,1,h,w) fp32 + a checksum of all
+        heads"""
+        hi = dv.n_slices(axis) if hi is None else hi
+        h, w = dv.plane_shape(axis)
+        prob = torch.empty((hi - lo, 1, h, w), dtype=torch.float32, device=self.device)
         chk = torch.zeros((), dtype=torch.float64, device=self.device)
-        a = 1.0 / (255.0 * NORM['std'])
-        b = -NORM['mean'] / NORM['std']
-        for s in range(0, D, self.batch):
-            x = vol[s:s + self.batch].unsqueeze(1).to(self.dtype).mul_(a).add_(b)
-            x = x.contiguous(memory_format=torch.channels_last)
-            out = self.model(x)
-            prob[s:s + self.batch] = torch.sigmoid(out['sem_logits'].float())
+        for s, x in dv.batches(axis, self.batch, lo, hi):
+            if self.dtype != torch.float32:
+                x = x.to(self.dtype)
+            out = self.model(x.contiguous(memory_format=torch.channels_last))
+            prob[s - lo:s - lo + x.shape[0]] = torch.sigmoid(out['sem_logits'][..., :h, :w].float())
             chk += out['ctr_hmp'].float().sum(dtype=torch.float64) + out['offsets'].float().sum(dtype=torch.float64)
         return prob, chk + prob.sum(dtype=torch.float64)
 
@@ -184,11 +186,12 @@ def build_inputs_ortho(S, device, rank=0, world=1):
     shape = (S, S, S)
     b = shard_bounds(S, world)
     lo, hi = int(b[rank]), int(b[rank + 1])
-    em = SY.em_volume(shape, seed=1234)
+    from empanada_amd.data import DeviceVolume
+    dv = DeviceVolume(SY.em_volume(shape, seed=1234), NORM['mean'], NORM['std'], 16, device)
     lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321)
     heads, stacks = {}, {}
     for axis, ax in (('xy', 0), ('xz', 1), ('yz', 2)):
-        stacks[axis] = torch.from_numpy(np.ascontiguousarray(np.moveaxis(em, ax, 0)[lo:hi])).to(device)
+        stacks[axis] = (dv, axis, lo, hi)          # the rank's block of the plane: a strided view of the volume
         parts = {'sem': [], 'ctr_hmp': [], 'offsets': []}
         for s in range(lo, hi, 64):
             h = SY.planted_heads(lab, cls, axis, device=device, slices=slice(s, min(hi, s + 64)), seed=99 + s)
@@ -211,7 +214,7 @@ def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages):
     # (Queuing all three forwards up front does not work: ~14k launches exceed the HIP queue and the host blocks.)
     post = pipe.post_stream
     planes = ('xy', 'xz', 'yz')
-    prob, c = pipe.forward(stacks['xy'])
+    prob, c = pipe.forward(*stacks['xy'])
     chk = chk + c
     ev = torch.cuda.Event()
     ev.record()
@@ -226,7 +229,7 @@ def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages):
             t1 = time.perf_counter()
             if i + 1 < len(planes):
                 with torch.cuda.stream(torch.cuda.default_stream()):
-                    prob, c = pipe.forward(stacks[planes[i + 1]])
+                    prob, c = pipe.forward(*stacks[planes[i + 1]])
                     chk = chk + c
                     ev = torch.cuda.Event()
                     ev.record()
@@ -541,7 +544,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1 and args.cpu_slices > 0:
             log('cpu baseline')
-            res['cpu_baseline'] = cpu_baseline(args, vol, heads, args.cpu_slices)
+            res['cpu_baseline'] = cpu_baseline(args, vol.vol, heads, args.cpu_slices)
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res), flush=True)

@@ -42,6 +42,7 @@ SIGNATURES = {
     'emp_wino_gemm_fused': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _I, _P, _P]),
     'emp_wino_output_transform': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _P]),
     'emp_chain_class': (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _c.c_double, _c.c_double, _P, _P, _P, _P]),
+    'emp_slices_to_input': (_I, [_P, _L, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),

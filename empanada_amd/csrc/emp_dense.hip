@@ -281,3 +281,51 @@ extern "C" int emp_upsample_bilinear(const float *x, int N, int C, int h, int w,
     EMP_CHECK_LAUNCH("emp_upsample_bilinear");
     return EMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// D0: slice feeder.  A resident uint8 volume is cut along any axis by element strides (xy slices are contiguous,
+// xz / yz slices are strided views: no host transposes, no extra copies), normalised like the reference's
+// albumentations Normalize (fp32: (x - mean*255) * (1 / (std*255))) and zero-padded to (hp, wp) in one pass.
+__global__ __launch_bounds__(256) void slices_to_input_kernel(const uint8_t *__restrict__ vol, int64_t s_slice,
+                                                             int64_t s_row, int64_t s_col, int n, int h, int w, int hp,
+                                                             int wp, float mean255, float inv_std255,
+                                                             float *__restrict__ out)
+{
+    const int wq = (wp + 3) >> 2;
+    const int64_t total = (int64_t)n * hp * wq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % wq) * 4;
+        const int64_t q = i / wq;
+        const int r = (int)(q % hp);
+        const int64_t s = q / hp;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < h) {
+            const uint8_t *src = vol + s * s_slice + (int64_t)r * s_row;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < w) v[j] = __fmul_rn(__fsub_rn((float)src[(int64_t)(c0 + j) * s_col], mean255), inv_std255);
+        }
+        float *dst = out + (s * hp + r) * (int64_t)wp + c0;
+        if (c0 + 3 < wp && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < wp) dst[j] = v[j];
+        }
+    }
+}
+
+extern "C" int emp_slices_to_input(const uint8_t *vol, int64_t stride_slice, int64_t stride_row, int64_t stride_col,
+                                   int n_slices, int h, int w, int hp, int wp, float mean255, float inv_std255,
+                                   float *out, void *stream)
+{
+    EMP_REQUIRE(vol && out, "slices_to_input: null pointer");
+    EMP_REQUIRE(n_slices >= 0 && h > 0 && w > 0 && hp >= h && wp >= w, "slices_to_input: bad shape");
+    if (n_slices == 0) return EMP_OK;
+    const int64_t total = (int64_t)n_slices * hp * ((wp + 3) / 4);
+    hipLaunchKernelGGL(slices_to_input_kernel, dim3(emp_grid(total, 256, 16384)), dim3(256), 0, emp_stream(stream), vol,
+                       stride_slice, stride_row, stride_col, n_slices, h, w, hp, wp, mean255, inv_std255, out);
+    EMP_CHECK_LAUNCH("emp_slices_to_input");
+    return EMP_OK;
+}

@@ -1,0 +1,75 @@
+"""Device-resident slice feeder: the reference reads one slice at a time from a zarr / ndarray on the
+host (`empanada/data/volume_dataset.py:7-53`), normalises it with albumentations and pads it; here the uint8 volume
+lives in HBM (1 GiB at 1024^3) and every plane is a strided view of it -- `emp_slices_to_input` gathers, normalises
+and pads a batch of slices in one pass, for any of the three axes, without transposed copies.
+
+Normalisation arithmetic: albumentations.Normalize(mean, std, max_pixel_value=255) computes, in fp32,
+(x - mean*255) * (1 / (std*255)).  albumentations is not installed in this image, so this restates its published
+formula: parity with the library is unpinned; the kernel is checked bit for bit against a numpy statement of the formula.
+"""
+import numpy as np
+import torch
+
+from . import _hip
+
+__all__ = ['DeviceVolume', 'normalize_constants', 'AXES']
+
+AXES = {'xy': 0, 'xz': 1, 'yz': 2}
+
+
+def normalize_constants(mean, std, max_pixel_value=255.0):
+    """(mean*255, 1/(std*255)) as fp32, computed like albumentations does (fp32 products, fp32 reciprocal)"""
+    m = np.float32(mean) * np.float32(max_pixel_value)
+    s = np.float32(std) * np.float32(max_pixel_value)
+    return float(m), float(np.reciprocal(s, dtype=np.float32))
+
+
+class DeviceVolume:
+    """A (D, H, W) uint8 volume resident on the GPU, served as normalised, padded (B, 1, hp, wp) fp32 batches along
+    any axis.  `len(dv.plane(axis))` slices of shape dv.plane_shape(axis); padding to a multiple of `factor`
+    (factor_pad, inference/postprocess.py:25-36)."""
+
+    def __init__(self, volume, mean, std, factor=16, device='cuda'):
+        v = torch.as_tensor(np.ascontiguousarray(volume) if isinstance(volume, np.ndarray) else volume)
+        assert v.dtype == torch.uint8 and v.dim() == 3, "uint8 (D, H, W) volume expected"
+        self.vol = v.to(device).contiguous()
+        self.shape = tuple(self.vol.shape)
+        self.factor = int(factor)
+        self.mean255, self.inv_std255 = normalize_constants(mean, std)
+
+    def n_slices(self, axis):
+        return self.shape[AXES[axis]]
+
+    def plane_shape(self, axis):
+        d = AXES[axis]
+        return tuple(s for i, s in enumerate(self.shape) if i != d)
+
+    def padded_shape(self, axis):
+        h, w = self.plane_shape(axis)
+        f = self.factor
+        return (-(-h // f) * f, -(-w // f) * f)
+
+    def _strides(self, axis):
+        D, H, W = self.shape
+        st = (H * W, W, 1)
+        d = AXES[axis]
+        rest = [i for i in range(3) if i != d]
+        return st[d], st[rest[0]], st[rest[1]]
+
+    def batch(self, axis, lo, hi):
+        """slices [lo, hi) of the plane -> (hi-lo, 1, hp, wp) fp32 (memory is NCHW == NHWC for one channel)"""
+        _hip.require_gpu()
+        n = hi - lo
+        assert 0 <= lo <= hi <= self.n_slices(axis)
+        h, w = self.plane_shape(axis)
+        hp, wp = self.padded_shape(axis)
+        ss, sr, sc = self._strides(axis)
+        out = torch.empty((n, 1, hp, wp), dtype=torch.float32, device=self.vol.device)
+        _hip.call('emp_slices_to_input', self.vol.data_ptr() + lo * ss, ss, sr, sc, n, h, w, hp, wp, self.mean255,
+                  self.inv_std255, out.data_ptr(), _hip.stream(), alg_bytes=n * h * w + 4 * out.numel())
+        return out
+
+    def batches(self, axis, batch, lo=0, hi=None):
+        hi = self.n_slices(axis) if hi is None else hi
+        for s in range(lo, hi, batch):
+            yield s, self.batch(axis, s, min(hi, s + batch))

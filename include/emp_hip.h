@@ -42,6 +42,17 @@ const char *emp_last_error(void);
 /* Number of visible HIP devices (does not create a context). */
 int emp_device_count(void);
 
+/* ---- D0: slice feeder: uint8 volume -> normalised, zero-padded fp32 model input ---------------------
+ * replaces VolumeDataset.__getitem__ + albumentations Normalize + factor_pad for a device-resident volume
+ *          empanada/data/volume_dataset.py:7-53, inference/postprocess.py:25-36 (factor_pad)
+ * Slice s, row r, column c of the chosen plane is vol[s*stride_slice + r*stride_row + c*stride_col] (element
+ * strides; xy: (H*W, W, 1), xz: (W, H*W, 1), yz: (1, H*W, W) for a (D,H,W) volume), so no transposed copy of the
+ * volume is ever made.  out (n_slices, 1, hp, wp) fp32 = (x - mean255) * inv_std255 (two fp32 roundings, the
+ * arithmetic of albumentations' Normalize with max_pixel_value = 255), rows >= h and columns >= w zero.       */
+int emp_slices_to_input(const uint8_t *vol, int64_t stride_slice, int64_t stride_row, int64_t stride_col,
+                        int n_slices, int h, int w, int hp, int wp, float mean255, float inv_std255,
+                        float *out, void *stream);
+
 /* ---- D1 epilogue: fused BatchNorm(eval) + residual + ReLU on NHWC fp32 activations -----------------
  * replaces the elementwise tail of every conv block of the dense path:
  *          Bottleneck / BasicBlock forward         empanada/models/encoders/resnet.py:66-82,110-128

@@ -550,3 +550,26 @@ def test_winograd_conv(hip, cfg):
                      + sh.view(1, -1, 1, 1))
     bound = torch.nn.functional.conv2d(x.abs(), w.abs(), None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1)
     assert torch.all((got.cpu() - ref).abs() <= 1e-5 * bound + 1e-6)
+
+
+@pytest.mark.parametrize('shape', [(6, 20, 37), (5, 16, 32), (3, 33, 7)])
+def test_device_volume_feeder(hip, shape):
+    """emp_slices_to_input: all three planes of a resident uint8 volume, bit-exact against the numpy statement of
+    albumentations' Normalize formula (fp32 (x - mean*255) * (1/(std*255))) + factor_pad."""
+    from empanada_amd.data import DeviceVolume, normalize_constants
+    rng = np.random.default_rng(shape[0])
+    vol = rng.integers(0, 256, shape, dtype=np.uint8)
+    mean, std = 0.508979, 0.148561
+    dv = DeviceVolume(vol, mean, std, factor=16)
+    m255, inv = normalize_constants(mean, std)
+    for axis, ax in (('xy', 0), ('xz', 1), ('yz', 2)):
+        planes = np.moveaxis(vol, ax, 0)
+        n, h, w = planes.shape
+        hp, wp = dv.padded_shape(axis)
+        assert hp % 16 == 0 and wp % 16 == 0 and hp >= h and wp >= w and dv.n_slices(axis) == n
+        exp = np.zeros((n, 1, hp, wp), dtype=np.float32)
+        exp[:, 0, :h, :w] = (planes.astype(np.float32) - np.float32(m255)) * np.float32(inv)
+        got = torch.cat([b for _, b in dv.batches(axis, 4)], dim=0).cpu().numpy()
+        np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+        lo, hi = 1, n - 1
+        np.testing.assert_array_equal(dv.batch(axis, lo, hi).cpu().numpy(), exp[lo:hi])
