@@ -289,7 +289,7 @@ def main_orthoplane(args, device, rank, world):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
@@ -378,9 +378,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     import torch.distributed as dist
+    backend = os.environ.get('EMP_BENCH_BACKEND', 'nccl')     # 'gloo': rehearse N ranks on fewer GPUs (not a measurement)
+    if backend == 'gloo':
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl')
+        dist.init_process_group(backend)
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     from empanada_amd import _hip
@@ -469,7 +472,7 @@ def main():
     prof, _hip.PROFILE = _hip.PROFILE, None
     _hip.PROFILE_SKIP.clear()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

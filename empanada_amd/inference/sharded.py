@@ -154,6 +154,11 @@ def _all_gather_cat(t, group=None):
     rank, world = _world()
     if world == 1:
         return t
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        # rehearsal mode (several ranks on one GPU, `EMP_BENCH_BACKEND=gloo`): stage through the host
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
+        dist.all_gather(parts, t.contiguous().cpu(), group=group)
+        return torch.cat(parts, dim=0).to(t.device)
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous(), group=group)
     return out
