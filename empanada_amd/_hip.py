@@ -43,6 +43,8 @@ SIGNATURES = {
     'emp_wino_output_transform': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _P]),
     'emp_chain_class': (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _c.c_double, _c.c_double, _P, _P, _P, _P]),
     'emp_slices_to_input': (_I, [_P, _L, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
+    'emp_pointwise_out_nhwc': (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),
+    'emp_bn_relu_maxpool_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
@@ -580,3 +582,28 @@ def wino_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, o
     call('emp_wino_output_transform', _ptr(Mw), _ptr(tiles_dev), T, N, H, W, Cout, dil, _ptr(scale), _ptr(shift),
          int(bool(relu)), out.data_ptr(), ops, st, alg_bytes=4 * (Mw.numel() + N * Cout * H * W))
     return out
+
+
+def pointwise_out_nhwc(x, w, bias=None):
+    """1x1 convolution to 1..4 channels: x (N,C,H,W) fp32 channels_last, w (Cout, C) -> (N,Cout,H,W) contiguous
+    (planar) fp32 (emp_pointwise_out_nhwc)."""
+    require_gpu()
+    N, C, H, W = x.shape
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    Cout = w.shape[0]
+    out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
+    call('emp_pointwise_out_nhwc', x.data_ptr(), _ptr(w), _ptr(bias), N * H * W, H * W, C, Cout, _ptr(out), stream(),
+         alg_bytes=4 * (x.numel() + out.numel()))
+    return out
+
+
+def bn_relu_maxpool_nhwc(x, scale, shift):
+    """max_pool2d(relu(x*scale + shift), 3, 2, 1) on x (N,C,H,W) fp32 channels_last (emp_bn_relu_maxpool_nhwc)."""
+    require_gpu()
+    N, C, H, W = x.shape
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    y = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device,
+                    memory_format=torch.channels_last)
+    call('emp_bn_relu_maxpool_nhwc', x.data_ptr(), _ptr(scale), _ptr(shift), N, H, W, C, y.data_ptr(), stream(),
+         alg_bytes=4 * (x.numel() + y.numel()))
+    return y

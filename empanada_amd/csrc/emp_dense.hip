@@ -329,3 +329,145 @@ extern "C" int emp_slices_to_input(const uint8_t *vol, int64_t stride_slice, int
     EMP_CHECK_LAUNCH("emp_slices_to_input");
     return EMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// D6: 1x1 convolution to a few output channels (the last layer of every head: 256 -> 1 or 2, bias).  Pure streaming:
+// one wave per pixel, lane l holds the channel groups l, l + 64, ... (float4 each) and the matching weights in
+// registers; per pixel and output channel an fma chain per lane, then a butterfly sum over the wave
+// (xor 32, 16, 8, 4, 2, 1 -- every lane ends with the same value).  64 pixels per wave iteration so that the
+// results are written as one coalesced row.  Output is planar (N, Cout, H*W): what the up-sampling and the
+// post-processing kernels read.
+template <int CO, int G>   // CO output channels, G float4 groups per lane
+__global__ __launch_bounds__(256) void pointwise_out_kernel(const float4 *__restrict__ x, const float4 *__restrict__ w,
+                                                            const float *__restrict__ bias, int64_t P, int64_t HW,
+                                                            int C4, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float4 wt[CO][G];
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int c4 = lane + 64 * g;
+            wt[co][g] = c4 < C4 ? w[co * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    float b[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) b[co] = bias ? bias[co] : 0.f;
+    for (int64_t p0 = wave * 64; p0 < P; p0 += n_waves * 64) {
+        float res[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) res[co] = 0.f;
+        const int np = (int)min((int64_t)64, P - p0);
+        for (int j0 = 0; j0 < np; j0 += 4) {
+            float4 v[4][G];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int c4 = lane + 64 * g;
+                    v[q][g] = (j0 + q < np && c4 < C4) ? x[(p0 + j0 + q) * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        s = __fmaf_rn(v[q][g].x, wt[co][g].x, s);
+                        s = __fmaf_rn(v[q][g].y, wt[co][g].y, s);
+                        s = __fmaf_rn(v[q][g].z, wt[co][g].z, s);
+                        s = __fmaf_rn(v[q][g].w, wt[co][g].w, s);
+                    }
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) s = __fadd_rn(s, __shfl_xor(s, o));
+                    if (lane == j0 + q) res[co] = __fadd_rn(s, b[co]);
+                }
+        }
+        if (lane < np) {
+            const int64_t p = p0 + lane;
+            const int64_t n = p / HW, r = p - n * HW;
+#pragma unroll
+            for (int co = 0; co < CO; ++co) out[(n * CO + co) * HW + r] = res[co];
+        }
+    }
+}
+
+extern "C" int emp_pointwise_out_nhwc(const float *x, const float *w, const float *bias, int64_t n_pixels,
+                                      int64_t pixels_per_image, int C, int Cout, float *out, void *stream)
+{
+    EMP_REQUIRE(x && w && out, "pointwise_out: null pointer");
+    EMP_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "pointwise_out: C %d must be a multiple of 4, at most 1024", C);
+    EMP_REQUIRE(Cout >= 1 && Cout <= 4, "pointwise_out: Cout %d not in 1..4", Cout);
+    EMP_REQUIRE(n_pixels >= 0 && pixels_per_image > 0 && n_pixels % pixels_per_image == 0, "pointwise_out: bad sizes");
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0, "pointwise_out: alignment");
+    if (n_pixels == 0) return EMP_OK;
+    const int C4 = C / 4, G = (C4 + 63) / 64;
+    const int grid = emp_grid(emp_cdiv(n_pixels, 64) * 64, 256, 8192);
+    hipStream_t st = emp_stream(stream);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *w4 = reinterpret_cast<const float4 *>(w);
+#define EMP_PW(CO, GG) hipLaunchKernelGGL((pointwise_out_kernel<CO, GG>), dim3(grid), dim3(256), 0, st, x4, w4, bias, n_pixels, pixels_per_image, C4, out)
+#define EMP_PW_G(CO) do { if (G == 1) EMP_PW(CO, 1); else if (G == 2) EMP_PW(CO, 2); else if (G == 3) EMP_PW(CO, 3); else EMP_PW(CO, 4); } while (0)
+    if (Cout == 1) EMP_PW_G(1);
+    else if (Cout == 2) EMP_PW_G(2);
+    else if (Cout == 3) EMP_PW_G(3);
+    else EMP_PW_G(4);
+#undef EMP_PW_G
+#undef EMP_PW
+    EMP_CHECK_LAUNCH("emp_pointwise_out_nhwc");
+    return EMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// D7: stem epilogue: eval-BatchNorm + ReLU + MaxPool2d(3, stride 2, padding 1) in one pass over the NHWC output of
+// the first convolution (4x more pixels than anything downstream): reads it once, writes the pooled quarter.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float4 *__restrict__ x, const float4 *__restrict__ scale,
+                                                              const float4 *__restrict__ shift, int N, int H, int W,
+                                                              int C4, int OH, int OW, float4 *__restrict__ y)
+{
+    const int64_t total = (int64_t)N * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int ox = (int)(p % OW);
+        p /= OW;
+        const int oy = (int)(p % OH);
+        const int n = (int)(p / OH);
+        const float4 a = scale[c4], b = shift[c4];
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = 2 * oy + dy, xx = 2 * ox + dx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const float4 v = x[(((int64_t)n * H + yy) * W + xx) * C4 + c4];
+                    m.x = fmaxf(m.x, fmaxf(__fadd_rn(__fmul_rn(v.x, a.x), b.x), 0.f));
+                    m.y = fmaxf(m.y, fmaxf(__fadd_rn(__fmul_rn(v.y, a.y), b.y), 0.f));
+                    m.z = fmaxf(m.z, fmaxf(__fadd_rn(__fmul_rn(v.z, a.z), b.z), 0.f));
+                    m.w = fmaxf(m.w, fmaxf(__fadd_rn(__fmul_rn(v.w, a.w), b.w), 0.f));
+                }
+            }
+        y[i] = m;
+    }
+}
+
+extern "C" int emp_bn_relu_maxpool_nhwc(const float *x, const float *scale, const float *shift, int N, int H, int W,
+                                        int C, float *y, void *stream)
+{
+    EMP_REQUIRE(x && scale && shift && y, "bn_relu_maxpool: null pointer");
+    EMP_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bn_relu_maxpool: bad shape");
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(scale) |
+                  reinterpret_cast<uintptr_t>(shift)) & 15) == 0, "bn_relu_maxpool: alignment");
+    if (N == 0) return EMP_OK;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(emp_grid(total, 256, 16384)), dim3(256), 0, emp_stream(stream),
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
+                       reinterpret_cast<const float4 *>(shift), N, H, W, C / 4, OH, OW, reinterpret_cast<float4 *>(y));
+    EMP_CHECK_LAUNCH("emp_bn_relu_maxpool_nhwc");
+    return EMP_OK;
+}

@@ -109,6 +109,27 @@ class FusedBNAct(nn.Module):
         return _hip.bn_act_nhwc_(x, self.scale, self.shift, residual, self.relu, out)
 
 
+class PointwiseOutNHWC(nn.Module):
+    """Inference-only stand-in for the heads' last Conv2d(C, n <= 4, 1, bias): emp_pointwise_out_nhwc, a streaming
+    pass instead of a GEMM-shaped MIOpen kernel.  Output is planar (N, n, H, W)."""
+
+    def __init__(self, conv):
+        super().__init__()
+        self.register_buffer('w', conv.weight.detach().float().reshape(conv.out_channels, conv.in_channels).contiguous())
+        self.register_buffer('b', conv.bias.detach().float().contiguous() if conv.bias is not None else None)
+
+    @staticmethod
+    def eligible(m):
+        return (isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0)
+                and m.groups == 1 and m.out_channels <= 4 and m.in_channels % 4 == 0 and m.in_channels <= 1024)
+
+    def forward(self, x):
+        from .. import _hip
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        return _hip.pointwise_out_nhwc(x, self.w, self.b)
+
+
 class FusedConvBNAct(nn.Module):
     """Conv2d + FusedBNAct (+ residual) as one call with three interchangeable implementations:
       'miopen' : MIOpen convolution, then the emp_bn_act_nhwc epilogue pass              (default)
@@ -299,8 +320,17 @@ class ResNetEncoder(nn.Module):
         mods += [block(self.inplanes, planes, dilation=dilation) for _ in range(1, blocks)]
         return nn.Sequential(*mods)
 
+    hip_ops = False
+
     def forward(self, x):
-        if isinstance(self.bn1, FusedBNAct):
+        if (self.hip_ops and isinstance(self.bn1, FusedBNAct) and x.is_cuda and x.dtype == torch.float32
+                and self.maxpool.kernel_size == 3 and self.maxpool.stride == 2 and self.maxpool.padding == 1):
+            from .. import _hip
+            y = self.conv1(x)
+            if not y.is_contiguous(memory_format=torch.channels_last):
+                y = y.contiguous(memory_format=torch.channels_last)
+            p1 = _hip.bn_relu_maxpool_nhwc(y, self.bn1.scale, self.bn1.shift)       # stem epilogue in one pass
+        elif isinstance(self.bn1, FusedBNAct):
             p1 = self.maxpool(self.bn1(self.conv1(x)))
         else:
             p1 = self.maxpool(self.relu(self.bn1(self.conv1(x))))
@@ -645,8 +675,11 @@ def tune_fused_convs(model, example, reps=5, verbose=False):
 
 
 def swap_depthwise(model):
-    """Swap every stride-1 depthwise Conv2d (3x3 / 5x5, zero "same" padding) for DepthwiseConvNHWC."""
+    """Swap every stride-1 depthwise Conv2d (3x3 / 5x5, zero "same" padding) for DepthwiseConvNHWC, and the last
+    1x1 convolution of every head for PointwiseOutNHWC."""
     for m in model.modules():
+        if isinstance(m, PanopticDeepLabHead) and PointwiseOutNHWC.eligible(m.head[1]):
+            m.head[1] = PointwiseOutNHWC(m.head[1])
         for name, child in list(m.named_children()):
             if DepthwiseConvNHWC.eligible(child):
                 if isinstance(m, nn.Sequential):

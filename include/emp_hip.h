@@ -138,6 +138,22 @@ int emp_wino_output_transform(const float *Mw, const int32_t *tiles, int64_t T, 
                               int Cout, int dil, const float *scale, const float *shift, int relu,
                               float *out, int64_t out_pixel_stride, void *stream);
 
+/* ---- D6: 1x1 convolution to 1..4 output channels on NHWC fp32 activations (last layer of every head) ----
+ * replaces the final nn.Conv2d(nin, n_classes, 1, bias=True) of PanopticDeepLabHead   empanada/models/heads.py:9-19
+ * out[n, co, r] = bias[co] + sum_c x[n*HW + r, c] * w[co, c]; evaluated per wave lane l as an fp32 fma chain from +0
+ * over its channel groups (channels 4g..4g+3 of groups g = l, l+64, ...), then a butterfly sum over the 64 lanes
+ * (pairs at lane distance 32, 16, 8, 4, 2, 1; each step one fp32 add), then + bias.  x (n_pixels, C) NHWC,
+ * w (Cout, C), out planar (N, Cout, pixels_per_image).  C % 4 == 0, C <= 1024, Cout <= 4.                    */
+int emp_pointwise_out_nhwc(const float *x, const float *w, const float *bias, int64_t n_pixels,
+                           int64_t pixels_per_image, int C, int Cout, float *out, void *stream);
+
+/* ---- D7: BatchNorm(eval) + ReLU + MaxPool2d(3, stride 2, padding 1) on NHWC fp32 (ResNet stem) ------------
+ * replaces bn1 -> relu -> maxpool of ResNet.forward             empanada/models/encoders/resnet.py:217-222
+ * y[n, oy, ox, c] = max over the 3x3 window (taps outside the image skipped) of max(x*scale[c] + shift[c], 0),
+ * multiply and add separate fp32 roundings.  x (N,H,W,C), y (N, (H-1)/2+1, (W-1)/2+1, C), C % 4 == 0.         */
+int emp_bn_relu_maxpool_nhwc(const float *x, const float *scale, const float *shift, int N, int H, int W,
+                             int C, float *y, void *stream);
+
 /* ---- P1 + P2: recursive median over a resident stack, fused with hardening ----------------
  * replaces _MedianQueue.get_next/get_median/end   empanada/inference/engines.py:47-90
  *          _harden_seg / harden_seg               engines.py:114-121, inference/patterns.py:242-251

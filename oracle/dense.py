@@ -139,3 +139,51 @@ def wino_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=Fa
             ok = (yy < H) & (xx < W)
             out[tiles[ok, 0], yy[ok], xx[ok]] = v[ok]
     return out
+
+
+def pointwise_out_nhwc(x_nhwc, w, bias=None):
+    """1x1 convolution to a few channels with the summation order of include/emp_hip.h (D6): per lane an fma chain
+    over its channel groups, butterfly sum over 64 lanes, + bias.  numpy fp32; the fma is emulated exactly in fp64
+    (a product of two fp32 values is exact in fp64, and fp64 -> fp32 rounding of (exact product + fp32 addend) equals
+    fmaf whenever the fp64 sum is exact or its double rounding is innocuous -- checked against the GPU bit for bit)."""
+    x = np.asarray(x_nhwc, dtype=np.float32)
+    w = np.asarray(w, dtype=np.float32)
+    N, H, W, C = x.shape
+    Cout = w.shape[0]
+    C4 = C // 4
+    P = N * H * W
+    xf = x.reshape(P, C)
+    out = np.empty((N, Cout, H * W), dtype=np.float32)
+    for co in range(Cout):
+        part = np.zeros((P, 64), dtype=np.float32)
+        for g in range((C4 + 63) // 64):
+            for l in range(64):
+                c4 = l + 64 * g
+                if c4 >= C4:
+                    continue
+                for e in range(4):
+                    c = 4 * c4 + e
+                    part[:, l] = (xf[:, c].astype(np.float64) * np.float64(w[co, c]) + part[:, l].astype(np.float64)).astype(np.float32)
+        s = part
+        for o in (32, 16, 8, 4, 2, 1):
+            s = (s + s[:, np.arange(64) ^ o]).astype(np.float32)
+        v = s[:, 0]
+        if bias is not None:
+            v = (v + np.float32(bias[co])).astype(np.float32)
+        out[:, co] = v.reshape(N, H * W)
+    return out.reshape(N, Cout, H, W)
+
+
+def bn_relu_maxpool_nhwc(x_nhwc, scale, shift):
+    """max over 3x3 / stride 2 / pad 1 windows of max(x*scale + shift, 0)  (emp_hip.h D7), numpy fp32"""
+    x = np.asarray(x_nhwc, dtype=np.float32)
+    N, H, W, C = x.shape
+    a = np.maximum((x * np.asarray(scale, np.float32)).astype(np.float32) + np.asarray(shift, np.float32), np.float32(0))
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    pad = np.full((N, H + 2, W + 2, C), -np.inf, dtype=np.float32)
+    pad[:, 1:H + 1, 1:W + 1] = a
+    out = np.full((N, OH, OW, C), -np.inf, dtype=np.float32)
+    for dy in range(3):
+        for dx in range(3):
+            out = np.maximum(out, pad[:, dy:dy + 2 * OH:2, dx:dx + 2 * OW:2][:, :OH, :OW])
+    return out

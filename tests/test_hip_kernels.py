@@ -573,3 +573,41 @@ def test_device_volume_feeder(hip, shape):
         np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
         lo, hi = 1, n - 1
         np.testing.assert_array_equal(dv.batch(axis, lo, hi).cpu().numpy(), exp[lo:hi])
+
+
+@pytest.mark.parametrize('cfg', [(2, 7, 9, 256, 1), (1, 5, 6, 256, 2), (3, 4, 4, 64, 4), (1, 9, 8, 320, 3),
+                                 (2, 16, 17, 128, 2)])
+def test_pointwise_out(hip, cfg):
+    """emp_pointwise_out_nhwc: bit-exact against the numpy restatement of its summation order; within fp32 rounding
+    of torch's conv2d (1e-5 * sum|x||w| + 1e-6)."""
+    from oracle import dense as OD
+    N, H, W, C, Cout = cfg
+    g = torch.Generator().manual_seed(C + Cout + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Cout, C, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    got = hip.pointwise_out_nhwc(xd, w.cuda(), b.cuda())
+    assert got.is_contiguous() and got.shape == (N, Cout, H, W)
+    exp = OD.pointwise_out_nhwc(x.permute(0, 2, 3, 1).numpy(), w.numpy(), b.numpy())
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    ref = torch.nn.functional.conv2d(x, w.view(Cout, C, 1, 1), b)
+    bound = torch.nn.functional.conv2d(x.abs(), w.abs().view(Cout, C, 1, 1))
+    assert torch.all((got.cpu() - ref).abs() <= 1e-5 * bound + 1e-6)
+    nob = hip.pointwise_out_nhwc(xd, w.cuda(), None)
+    np.testing.assert_array_equal(nob.cpu().numpy().view(np.uint32),
+                                  OD.pointwise_out_nhwc(x.permute(0, 2, 3, 1).numpy(), w.numpy(), None).view(np.uint32))
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 16, 16), (1, 8, 7, 9), (3, 4, 1, 5), (1, 64, 33, 32)])
+def test_bn_relu_maxpool(hip, shape):
+    from oracle import dense as OD
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    got = hip.bn_relu_maxpool_nhwc(x.cuda().contiguous(memory_format=torch.channels_last), sc.cuda(), sh.cuda())
+    exp = OD.bn_relu_maxpool_nhwc(x.permute(0, 2, 3, 1).numpy(), sc.numpy(), sh.numpy())
+    np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    ref = torch.nn.functional.max_pool2d(torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 3, 2, 1)
+    assert torch.equal(got.cpu(), ref)
