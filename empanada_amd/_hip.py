@@ -39,6 +39,8 @@ SIGNATURES = {
     'emp_conv_bn_act_nhwc': (_I, [_P, _P, _P, _P, _P, _L, _I] + [_I] * 10 + [_P, _L, _P]),
     'emp_wino_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     'emp_gemm_nt_batched': (_I, [_P, _P, _I, _L, _I, _I, _P, _P]),
+    'emp_wino4_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
+    'emp_wino4_output_transform': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _P]),
     'emp_wino_gemm_fused': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _I, _P, _P]),
     'emp_wino_output_transform': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _P]),
     'emp_chain_class': (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _c.c_double, _c.c_double, _P, _P, _P, _P]),
@@ -515,20 +517,21 @@ def conv_bn_act_nhwc(x, w_okkc, scale=None, shift=None, residual=None, relu=Fals
     return out
 
 
-def wino_tiles(N, H, W, dil):
-    """(T, 3) int32 numpy table of Winograd F(2x2,3x3) tiles for a 3x3 convolution with dilation dil and
-    padding dil: (n, y, x) of each tile's 4x4 patch origin, ordered (n, sub-grid row, sub-grid col, tile row, col)."""
+def wino_tiles(N, H, W, dil, m=2):
+    """(T, 3) int32 numpy table of Winograd F(m x m, 3x3) tiles (m = 2 or 4) for a 3x3 convolution with dilation
+    dil and padding dil: (n, y, x) of each tile's (m+2)x(m+2) patch origin, ordered (n, sub-grid row, sub-grid col,
+    tile row, col)."""
     import numpy as np
     rows = []
     for ry in range(min(dil, H)):
         hs = -(-(H - ry) // dil)
-        for ty in range(-(-hs // 2)):
-            rows.append(ry + dil * (2 * ty - 1))
+        for ty in range(-(-hs // m)):
+            rows.append(ry + dil * (m * ty - 1))
     cols = []
     for rx in range(min(dil, W)):
         ws = -(-(W - rx) // dil)
-        for tx in range(-(-ws // 2)):
-            cols.append(rx + dil * (2 * tx - 1))
+        for tx in range(-(-ws // m)):
+            cols.append(rx + dil * (m * tx - 1))
     # group by sub-grid: rows are already grouped by ry, cols by rx
     ys, xs = np.meshgrid(np.array(rows, dtype=np.int32), np.array(cols, dtype=np.int32), indexing='ij')
     per = np.stack([ys.ravel(), xs.ravel()], axis=1)
@@ -607,3 +610,45 @@ def bn_relu_maxpool_nhwc(x, scale, shift):
     call('emp_bn_relu_maxpool_nhwc', x.data_ptr(), _ptr(scale), _ptr(shift), N, H, W, C, y.data_ptr(), stream(),
          alg_bytes=4 * (x.numel() + y.numel()))
     return y
+
+
+def wino4_filter_transform(w_oihw):
+    """(Cout, Cin, 3, 3) -> U (36, Cout, Cin) = fp32(G g G^T) for F(4x4,3x3), evaluated elementwise in fp64 (rows
+    first, then columns): G rows = [1/4 0 0], [-1/6 -1/6 -1/6], [-1/6 1/6 -1/6], [1/24 1/12 1/6],
+    [1/24 -1/12 1/6], [0 0 1]."""
+    g = w_oihw.detach().double().cpu()
+
+    def comb(a, b, c):
+        return [a / 4.0, -((a + b) + c) / 6.0, ((b - a) - c) / 6.0, (a / 24.0 + b / 12.0) + c / 6.0,
+                (a / 24.0 - b / 12.0) + c / 6.0, c]
+
+    rows = comb(g[:, :, 0, :], g[:, :, 1, :], g[:, :, 2, :])
+    U = []
+    for r in rows:
+        U.extend(comb(r[:, :, 0], r[:, :, 1], r[:, :, 2]))
+    return torch.stack(U, dim=0).float().contiguous()
+
+
+def wino4_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, out=None):
+    """3x3 stride-1 convolution with padding == dilation through Winograd F(4x4,3x3) (emp_wino4_input_transform,
+    emp_gemm_nt_batched x 36, emp_wino4_output_transform); tiles from wino_tiles(..., m=4)."""
+    require_gpu()
+    N, Cin, H, W = x.shape
+    Cout = U.shape[1]
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    T = tiles_dev.shape[0]
+    V = torch.empty((36, T, Cin), dtype=torch.float32, device=x.device)
+    Mw = torch.empty((36, T, Cout), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    assert out.shape == (N, Cout, H, W) and out.stride(1) == 1
+    ops = out.stride(3)
+    assert out.stride(2) == W * ops and out.stride(0) == H * W * ops, "NHWC channel slice required"
+    st = stream()
+    call('emp_wino4_input_transform', x.data_ptr(), N, H, W, Cin, dil, _ptr(tiles_dev), T, _ptr(V), st,
+         alg_bytes=4 * (x.numel() + V.numel()))
+    call('emp_gemm_nt_batched', _ptr(V), _ptr(U), 36, T, Cout, Cin, _ptr(Mw), st,
+         alg_bytes=4 * (V.numel() + U.numel() + Mw.numel()), alg_flops=2 * 36 * T * Cout * Cin)
+    call('emp_wino4_output_transform', _ptr(Mw), _ptr(tiles_dev), T, N, H, W, Cout, dil, _ptr(scale), _ptr(shift),
+         int(bool(relu)), out.data_ptr(), ops, st, alg_bytes=4 * (Mw.numel() + N * Cout * H * W))
+    return out

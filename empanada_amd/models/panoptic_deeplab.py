@@ -136,6 +136,8 @@ class FusedConvBNAct(nn.Module):
       'direct' : emp_conv_bn_act_nhwc -- implicit GEMM on the fp32 matrix cores, epilogue fused
       'wino'   : Winograd F(2x2,3x3), input transform inside the GEMM loader -- emp_wino_gemm_fused /
                  emp_wino_output_transform
+      'wino4'  : Winograd F(4x4,3x3), 36 GEMMs, 4x fewer matrix-core FLOPs; rounding error about 10x the direct
+                 form's (emp_wino4_input_transform / emp_gemm_nt_batched / emp_wino4_output_transform)
       'wino_sep': the same with V materialised -- emp_wino_input_transform / emp_gemm_nt_batched /
                  emp_wino_output_transform (less L2 traffic per matrix-core FLOP; wins when Cin is large)
     tune_fused_convs() times the candidates on the layer's real shape and keeps the fastest."""
@@ -148,6 +150,7 @@ class FusedConvBNAct(nn.Module):
         self._seen = None
         self._w_okkc = None
         self._U = None
+        self._U4 = None
         self._tiles = {}
 
     def candidates(self, has_residual):
@@ -160,7 +163,7 @@ class FusedConvBNAct(nn.Module):
             out.append('direct')
             if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == c.dilation and c.out_channels % 4 == 0
                     and not has_residual):
-                out.extend(['wino', 'wino_sep'])
+                out.extend(['wino', 'wino_sep', 'wino4'])
         return out
 
     def _prepare(self, impl):
@@ -169,12 +172,17 @@ class FusedConvBNAct(nn.Module):
             self._w_okkc = self.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
         if impl in ('wino', 'wino_sep') and self._U is None:
             self._U = _hip.wino_filter_transform(self.conv.weight.detach())
+        if impl == 'wino4' and self._U4 is None:
+            self._U4 = _hip.wino4_filter_transform(self.conv.weight.detach()).to(self.conv.weight.device)
 
     def release(self, keep):
         if keep != 'direct':
             self._w_okkc = None
         if keep not in ('wino', 'wino_sep'):
             self._U = None
+        if keep != 'wino4':
+            self._U4 = None
+        if keep not in ('wino', 'wino_sep', 'wino4'):
             self._tiles = {}
 
     def forward(self, x, residual=None, out=None):
@@ -193,9 +201,13 @@ class FusedConvBNAct(nn.Module):
             return _hip.conv_bn_act_nhwc(x, self._w_okkc, self.bn.scale, self.bn.shift, residual, self.bn.relu,
                                          c.stride[0], c.padding[0], c.dilation[0], out)
         assert residual is None
-        key = (x.shape[0], x.shape[2], x.shape[3])
+        m = 4 if impl == 'wino4' else 2
+        key = (x.shape[0], x.shape[2], x.shape[3], m)
         if key not in self._tiles:
-            self._tiles[key] = torch.from_numpy(_hip.wino_tiles(key[0], key[1], key[2], c.dilation[0])).to(x.device)
+            self._tiles[key] = torch.from_numpy(_hip.wino_tiles(key[0], key[1], key[2], c.dilation[0], m)).to(x.device)
+        if impl == 'wino4':
+            return _hip.wino4_conv_bn_act(x, self._U4, self._tiles[key], c.dilation[0], self.bn.scale, self.bn.shift,
+                                          self.bn.relu, out)
         return _hip.wino_conv_bn_act(x, self._U, self._tiles[key], c.dilation[0], self.bn.scale, self.bn.shift,
                                      self.bn.relu, out, fused=(impl == 'wino'))
 

@@ -138,6 +138,23 @@ int emp_wino_output_transform(const float *Mw, const int32_t *tiles, int64_t T, 
                               int Cout, int dil, const float *scale, const float *shift, int relu,
                               float *out, int64_t out_pixel_stride, void *stream);
 
+/* ---- D5b: Winograd F(4x4, 3x3): the same three steps with 6x6 patches, 36 positions, 4x4 outputs per tile ----
+ * tiles: (T, 3) int32 (n, y, x) of the patch origin; outputs are (y + d + a*d, x + d + b*d), a, b in 0..3.
+ * Input transform  (B^T d B, columns first then rows), per 6-vector d:
+ *   r0 = (4 d0 - 5 d2) + d4;  r1 = (d3 + d4) - 4 (d1 + d2);  r2 = (d4 - d3) + 4 (d1 - d2);
+ *   r3 = (d4 - d2) + 2 (d3 - d1);  r4 = (d4 - d2) + 2 (d1 - d3);  r5 = (4 d1 - 5 d3) + d5
+ * Output transform (A^T m A, rows first then columns), per 6-vector m:
+ *   s0 = ((m0 + m1) + m2) + (m3 + m4);  s1 = (m1 - m2) + 2 (m3 - m4);  s2 = (m1 + m2) + 4 (m3 + m4);
+ *   s3 = ((m1 - m2) + 8 (m3 - m4)) + m5
+ * every operation one fp32 rounding.  V (36, T, C), position p = 6u + v; GEMMs: emp_gemm_nt_batched with batch 36
+ * and B = U (36, Cout, Cin) = fp32(G g G^T evaluated in fp64) prepared by the host.  Rounding error is about 10x
+ * that of the direct form (1.3e-6 * sum|x||w| measured at K = 18432): stated test tolerance 2e-5 * sum|x||w|.   */
+int emp_wino4_input_transform(const float *x, int N, int H, int W, int C, int dil, const int32_t *tiles,
+                              int64_t T, float *V, void *stream);
+int emp_wino4_output_transform(const float *Mw, const int32_t *tiles, int64_t T, int N, int H, int W,
+                               int Cout, int dil, const float *scale, const float *shift, int relu,
+                               float *out, int64_t out_pixel_stride, void *stream);
+
 /* ---- D6: 1x1 convolution to 1..4 output channels on NHWC fp32 activations (last layer of every head) ----
  * replaces the final nn.Conv2d(nin, n_classes, 1, bias=True) of PanopticDeepLabHead   empanada/models/heads.py:9-19
  * out[n, co, r] = bias[co] + sum_c x[n*HW + r, c] * w[co, c]; evaluated per wave lane l as an fp32 fma chain from +0

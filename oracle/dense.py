@@ -187,3 +187,73 @@ def bn_relu_maxpool_nhwc(x_nhwc, scale, shift):
         for dx in range(3):
             out = np.maximum(out, pad[:, dy:dy + 2 * OH:2, dx:dx + 2 * OW:2][:, :OH, :OW])
     return out
+
+
+def wino4_filter_transform(w_oihw):
+    """fp32(G g G^T) for F(4x4,3x3) in the elementwise fp64 order of empanada_amd._hip.wino4_filter_transform"""
+    g = np.asarray(w_oihw, dtype=np.float64)
+
+    def comb(a, b, c):
+        return [a / 4.0, -((a + b) + c) / 6.0, ((b - a) - c) / 6.0, (a / 24.0 + b / 12.0) + c / 6.0,
+                (a / 24.0 - b / 12.0) + c / 6.0, c]
+
+    rows = comb(g[:, :, 0, :], g[:, :, 1, :], g[:, :, 2, :])
+    U = []
+    for r in rows:
+        U.extend(comb(r[:, :, 0], r[:, :, 1], r[:, :, 2]))
+    return np.ascontiguousarray(np.stack(U, axis=0).astype(np.float32))
+
+
+def _bt4(d):
+    f = np.float32
+    return [(f(4) * d[0] - f(5) * d[2]) + d[4], (d[3] + d[4]) - f(4) * (d[1] + d[2]), (d[4] - d[3]) + f(4) * (d[1] - d[2]),
+            (d[4] - d[2]) + f(2) * (d[3] - d[1]), (d[4] - d[2]) + f(2) * (d[1] - d[3]), (f(4) * d[1] - f(5) * d[3]) + d[5]]
+
+
+def _at4(m):
+    f = np.float32
+    return [((m[0] + m[1]) + m[2]) + (m[3] + m[4]), (m[1] - m[2]) + f(2) * (m[3] - m[4]),
+            (m[1] + m[2]) + f(4) * (m[3] + m[4]), ((m[1] - m[2]) + f(8) * (m[3] - m[4])) + m[5]]
+
+
+def wino4_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=False):
+    """Winograd F(4x4,3x3) exactly as include/emp_hip.h (D5b) specifies it (numpy fp32, one rounding per operation;
+    GEMMs through the C fma-chain oracle)."""
+    x = np.asarray(x_nhwc, dtype=np.float32)
+    N, H, W, C = x.shape
+    U = wino4_filter_transform(w_oihw)
+    Cout = U.shape[1]
+    T = len(tiles)
+    off = 5 * dil + 8
+    xp = np.zeros((N, H + 2 * off, W + 2 * off, C), dtype=np.float32)
+    xp[:, off:off + H, off:off + W] = x
+    n, by, bx = tiles[:, 0], tiles[:, 1] + off, tiles[:, 2] + off
+    tt = [_bt4([xp[n, by + a * dil, bx + b * dil] for b in range(6)]) for a in range(6)]      # tt[a][v]
+    V = np.empty((36, T, C), dtype=np.float32)
+    for v in range(6):
+        r = _bt4([tt[a][v] for a in range(6)])
+        for u in range(6):
+            V[u * 6 + v] = r[u]
+    M = np.empty((36, T, Cout), dtype=np.float32)
+    for p in range(36):
+        M[p] = conv_bn_act_nhwc(V[p][None, None], U[p][:, None, None, :])[0, 0]
+    s = [[None] * 6 for _ in range(4)]
+    for b in range(6):
+        r = _at4([M[a * 6 + b] for a in range(6)])
+        for a in range(4):
+            s[a][b] = r[a]
+    out = np.zeros((N, H, W, Cout), dtype=np.float32)
+    for a in range(4):
+        yv = _at4(s[a])
+        for b in range(4):
+            v = yv[b]
+            if scale is not None:
+                v = (v * np.asarray(scale, dtype=np.float32)).astype(np.float32)
+            if shift is not None:
+                v = (v + np.asarray(shift, dtype=np.float32)).astype(np.float32)
+            if relu:
+                v = np.maximum(v, np.float32(0))
+            yy, xx = tiles[:, 1] + dil + a * dil, tiles[:, 2] + dil + b * dil
+            ok = (yy < H) & (xx < W)
+            out[tiles[ok, 0], yy[ok], xx[ok]] = v[ok]
+    return out
