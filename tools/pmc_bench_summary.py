@@ -22,7 +22,8 @@ def load(d, counter):
     for r in rows:
         name = r['Kernel_Name'].split('(')[0].replace('void ', '')
         if 'conv_igemm' in name:
-            name += ' [batched x16]' if gy.get(r['Dispatch_Id'], (1, 0))[0] == 16 else ''
+            g = gy.get(r['Dispatch_Id'], (1, 0))[0]
+            name += f' [batched x{g}]' if g > 1 else ''
         a = agg[name]
         a[0] += float(r['Counter_Value'])
         a[1] += 1
