@@ -36,6 +36,7 @@ SIGNATURES = {
     'emp_bn_act_nhwc': (_I, [_P, _P, _P, _P, _I, _L, _I, _P, _L, _P]),
     'emp_dwconv_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'emp_upsample_bilinear': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
+    'emp_conv_k_slab': (_I, [_L, _I, _I, _I]),
     'emp_conv_bn_act_nhwc': (_I, [_P, _P, _P, _P, _P, _L, _I] + [_I] * 10 + [_P, _L, _P]),
     'emp_wino_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     'emp_gemm_nt_batched': (_I, [_P, _P, _I, _L, _I, _I, _P, _P]),
@@ -652,3 +653,9 @@ def wino4_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, 
     call('emp_wino4_output_transform', _ptr(Mw), _ptr(tiles_dev), T, N, H, W, Cout, dil, _ptr(scale), _ptr(shift),
          int(bool(relu)), out.data_ptr(), ops, st, alg_bytes=4 * (Mw.numel() + N * Cout * H * W))
     return out
+
+
+def conv_k_slab(M, Cout, batch=1, has_residual=False):
+    """K-slab (16 or 32) emp_conv_bn_act_nhwc / emp_gemm_nt_batched use for an (M x Cout) output, `batch` GEMMs per
+    launch: fixes the summation order the oracle mirrors"""
+    return int(load().emp_conv_k_slab(int(M), int(Cout), int(batch), int(bool(has_residual))))

@@ -16,12 +16,12 @@
 //   (its own L2) works on a contiguous range of tiles, cout-tiles fastest, and the A slabs shared by the cout
 //   tiles of one pixel tile are fetched once per XCD.
 #include "emp_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CG_BM 128
-#define CG_BK 32
-#define CG_LD 36          // padded LDS row (floats)
+#define CG_BK 32          // K granularity every entry point requires of Cin / K
 #define CG_THREADS 256
 
 struct ConvGeom {
@@ -42,14 +42,26 @@ struct ConvGeom {
 //         wino_input_kernel.
 // RESPF: the residual values of the thread's epilogue rows are requested before the K loop (registers), so their
 //        HBM latency hides behind the matrix work instead of sitting in the epilogue (short-K 1x1 convs).
-template <int NT, int MODE, bool RESPF = false>
-__global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom g)
+// BK:    K-slab per barrier.  32: 64 MFMAs per wave between barriers, 72 KiB of LDS, 2 blocks per CU.
+//        16: 32 MFMAs between barriers, 40 KiB of LDS and <= 168 VGPRs, 3 blocks per CU: the prologue / epilogue of
+//        one block (global latency, LDS staging, stores) hides behind the matrix work of two others -- better for
+//        short K loops.  Inside a slab the k-step j consumes channels j and BK/2 + j.
+template <int NT, int MODE, bool RESPF = false, int BK = 32>
+__global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32_kernel(ConvGeom g)
 {
     constexpr int BN = 64 * NT;
-    constexpr int BROWS = BN / 32;                 // B rows staged per thread
+    constexpr int CG_LD = BK + 4;                  // padded LDS row (floats): 16-byte fragment reads conflict-free
+    constexpr int TPR = BK / 4;                    // threads staging one row (one float4 each)
+    constexpr int RPP = CG_THREADS / TPR;          // rows staged per pass
+    constexpr int AR = CG_BM / RPP;                // A rows staged per thread
+    constexpr int BROWS = BN / RPP;                // B rows staged per thread
+    constexpr int NF4 = BK / 8;                    // float4 fragments per lane, tile and slab
     constexpr int CLD = BN + 4;                    // padded row of the epilogue staging tile (floats)
-    constexpr int A_ELEMS = 2 * CG_BM * CG_LD, B_ELEMS = 2 * BN * CG_LD, C_ELEMS = CG_BM * CLD;
+    constexpr int A_ELEMS = 2 * CG_BM * CG_LD, B_ELEMS = 2 * BN * CG_LD;
+    constexpr int EPI_ROWS = (A_ELEMS + B_ELEMS >= CG_BM * CLD) ? CG_BM : 64;   // epilogue staged in 1 or 2 rounds
+    constexpr int C_ELEMS = EPI_ROWS * CLD;
     constexpr int SMEM = (A_ELEMS + B_ELEMS) > C_ELEMS ? (A_ELEMS + B_ELEMS) : C_ELEMS;
+    static_assert(MODE == 0 || BK == 32, "the fused Winograd loader is written for BK = 32");
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float *As = smem, *Bs = smem + A_ELEMS;
     g.x += (int64_t)blockIdx.y * g.x_bs;
@@ -66,11 +78,11 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
     const int n0 = tn * BN;
 
     const int tid = threadIdx.x;
-    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    const int lrow = tid / TPR, lcol = (tid % TPR) * 4;
 
     // the 4 A rows (output pixels / Winograd tiles) and BROWS B rows (couts) this thread stages, fixed over the K loop
-    int a_n[4], a_iy[4], a_ix[4];
-    bool a_ok[4], b_ok[BROWS];
+    int a_n[AR], a_iy[AR], a_ix[AR];
+    bool a_ok[AR], b_ok[BROWS];
     const float *b_ptr[BROWS];
     const int taps = g.KH * g.KW;
     int w_off[4][4];                   // MODE 1: element offsets of the 4 patch pixels of each row (0 when masked)
@@ -78,8 +90,8 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
     float w_su = 1.f, w_sv = 1.f;      // MODE 1: sign of the second operand of the row / column combination
     if constexpr (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t p = m0 + lrow + 32 * i;
+        for (int i = 0; i < AR; ++i) {
+            const int64_t p = m0 + lrow + RPP * i;
             a_ok[i] = p < g.M;
             const int64_t pp = a_ok[i] ? p : 0;
             const int ox = (int)(pp % g.OW);
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
-        const int co = n0 + lrow + 32 * i;
+        const int co = n0 + lrow + RPP * i;
         b_ok[i] = co < g.Cout;
         b_ptr[i] = g.w + (int64_t)(b_ok[i] ? co : 0) * taps * g.Cin + lcol;    // row 0 stands in for rows past Cout
     }
@@ -131,20 +143,20 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    const int cslabs = g.Cin / CG_BK;
+    const int cslabs = g.Cin / BK;
     const int S = taps * cslabs;
-    float4 ra[MODE == 0 ? 4 : 16], rb[BROWS];
+    float4 ra[MODE == 0 ? AR : 16], rb[BROWS];
 
     // Staging state of the NEXT slab to load: filter tap, channel offset, and per A row the source pointer of the
     // tap (rows whose tap falls outside the image, or past M, read a dummy address and are zeroed after the load:
     // no divergent branches around the loads).  Pointers are recomputed once per tap, not per slab.
     int ld_tap = 0, ld_c0 = 0;
-    const float *a_ptr[4];
-    bool a_in[4];
+    const float *a_ptr[AR];
+    bool a_in[AR];
     auto set_tap = [&](int tap) {
         const int ky = tap / g.KW, kx = tap - ky * g.KW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AR; ++i) {
             const int iy = a_iy[i] + ky * g.dil, ix = a_ix[i] + kx * g.dil;
             a_in[i] = a_ok[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
             a_ptr[i] = a_in[i] ? g.x + (((int64_t)a_n[i] * g.H + iy) * g.W + ix) * g.Cin + lcol : g.x + lcol;
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
     auto load_slab = [&]() {
         if constexpr (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_ptr[i] + ld_c0);
+            for (int i = 0; i < AR; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_ptr[i] + ld_c0);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const float4 *>(b_ptr[i] + (int64_t)ld_tap * g.Cin + ld_c0);
-        ld_c0 += CG_BK;
+        ld_c0 += BK;
         if (ld_c0 == g.Cin) {               // block-uniform
             ld_c0 = 0;
             ++ld_tap;
@@ -172,10 +184,10 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
         }
     };
     // a_in of the slab held in ra: captured before load_slab advances the tap
-    bool r_in[4];
+    bool r_in[AR];
     auto store_slab = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AR; ++i) {
             float4 v;
             if constexpr (MODE == 0) {
                 v = ra[i];
@@ -194,19 +206,19 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
                 v = CG_COMB(c0, c1, w_su);                        // along rows
 #undef CG_COMB
             }
-            *reinterpret_cast<float4 *>(&As[buf * CG_BM * CG_LD + (lrow + 32 * i) * CG_LD + lcol]) = v;
+            *reinterpret_cast<float4 *>(&As[buf * CG_BM * CG_LD + (lrow + RPP * i) * CG_LD + lcol]) = v;
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             float4 v = rb[i];
             if (!b_ok[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(&Bs[buf * BN * CG_LD + (lrow + 32 * i) * CG_LD + lcol]) = v;
+            *reinterpret_cast<float4 *>(&Bs[buf * BN * CG_LD + (lrow + RPP * i) * CG_LD + lcol]) = v;
         }
     };
 #define CG_LOAD_NEXT()                                   \
     do {                                                 \
         if constexpr (MODE == 0) {                       \
-            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) r_in[i_] = a_in[i_]; \
+            _Pragma("unroll") for (int i_ = 0; i_ < AR; ++i_) r_in[i_] = a_in[i_]; \
         }                                                \
         load_slab();                                     \
     } while (0)
@@ -236,10 +248,10 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
     __syncthreads();
     for (int s = 0; s < S; ++s) {
         const int buf = s & 1;
-        const float *Ab = &As[buf * CG_BM * CG_LD + (wm * 64 + r) * CG_LD + hh * 16];
-        const float *Bb = &Bs[buf * BN * CG_LD + (wn * 32 * NT + r) * CG_LD + hh * 16];
+        const float *Ab = &As[buf * CG_BM * CG_LD + (wm * 64 + r) * CG_LD + hh * (BK / 2)];
+        const float *Bb = &Bs[buf * BN * CG_LD + (wn * 32 * NT + r) * CG_LD + hh * (BK / 2)];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NF4 / 2; ++half) {
             float4 fa[2][2], fb[NT][2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -277,19 +289,10 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
     }
 
     // epilogue, staged through LDS so that global traffic is 16 bytes per lane and row-contiguous:
-    // accumulators -> LDS tile [128][BN] (C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)),
-    // then y = relu?(acc * scale[co] + shift[co] (+ residual)) written as float4 along cout.
+    // accumulators -> LDS tile [EPI_ROWS][BN] (C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)),
+    // then y = relu?(acc * scale[co] + shift[co] (+ residual)) written as float4 along cout.  With the small-LDS
+    // variant the tile is staged in two rounds of 64 rows (the rows of the waves wm = 0, then wm = 1).
     float *Cs = smem;                                  // the K loop ended with a barrier: As / Bs are free
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int row = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
-                Cs[row * CLD + wn * 32 * NT + j * 32 + r] = acc[i][j][q];
-            }
-    __syncthreads();
     const bool vec_ok = (co + 3 < g.Cout) && ((g.out_ps & 3) == 0) && ((g.res_ps & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) &&
                         (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 15) == 0) && ((g.Cout & 3) == 0);
@@ -300,42 +303,92 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_igemm_f32_kernel(ConvGeom 
             if (g.scale) sc[e] = g.scale[co + e];
             if (g.shift) sh[e] = g.shift[co + e];
         }
+    constexpr int ROUNDS = CG_BM / EPI_ROWS;
+    constexpr int NRR = EPI_ROWS / RPI;                // epilogue iterations per thread and round
 #pragma unroll
-    for (int it = 0; it < NRE; ++it) {
-        const int row = crow + it * RPI;
-        const int64_t p = m0 + row;
-        if (p < g.M) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(&Cs[row * CLD + ccol]);
-            float v[4] = {a4.x, a4.y, a4.z, a4.w};
-            float rr[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (RESPF) {
-                rr[0] = rpre[it].x; rr[1] = rpre[it].y; rr[2] = rpre[it].z; rr[3] = rpre[it].w;
-            } else if (g.res) {
-                if (vec_ok) {
-                    const float4 r4 = *reinterpret_cast<const float4 *>(g.res + p * g.res_ps + co);
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        if (rd > 0) __syncthreads();                   // the previous round's reads are done
+        if (ROUNDS == 1 || wm == rd) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = (ROUNDS == 1 ? wm * 64 : 0) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+                        Cs[row * CLD + wn * 32 * NT + j * 32 + r] = acc[i][j][q];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NRR; ++it) {
+            const int lrow_c = crow + it * RPI;            // row inside the staged chunk
+            const int row = rd * EPI_ROWS + lrow_c;        // row inside the block tile
+            const int64_t p = m0 + row;
+            if (p < g.M) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(&Cs[lrow_c * CLD + ccol]);
+                float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                float rr[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (RESPF) {
+                    const float4 r4 = rpre[rd * NRR + it];
                     rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w;
+                } else if (g.res) {
+                    if (vec_ok) {
+                        const float4 r4 = *reinterpret_cast<const float4 *>(g.res + p * g.res_ps + co);
+                        rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (co + e < g.Cout) rr[e] = g.res[p * g.res_ps + co + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (g.scale) v[e] = __fmul_rn(v[e], sc[e]);
+                    if (g.shift) v[e] = __fadd_rn(v[e], sh[e]);
+                    if (g.res) v[e] = __fadd_rn(v[e], rr[e]);
+                    if (g.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (vec_ok) {
+                    *reinterpret_cast<float4 *>(g.out + p * g.out_ps + co) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (co + e < g.Cout) rr[e] = g.res[p * g.res_ps + co + e];
+                        if (co + e < g.Cout) g.out[p * g.out_ps + co + e] = v[e];
                 }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (g.scale) v[e] = __fmul_rn(v[e], sc[e]);
-                if (g.shift) v[e] = __fadd_rn(v[e], sh[e]);
-                if (g.res) v[e] = __fadd_rn(v[e], rr[e]);
-                if (g.relu) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (vec_ok) {
-                *reinterpret_cast<float4 *>(g.out + p * g.out_ps + co) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (co + e < g.Cout) g.out[p * g.out_ps + co + e] = v[e];
             }
         }
     }
+}
+
+// Tile / K-slab selection, shared by the launchers and exported so that the oracle can mirror the summation order.
+// 16-wide slabs (three resident blocks per CU instead of two: each block's prologue / epilogue hides behind the
+// matrix work of two others) unless the launch has at most two blocks per CU anyway, or the residual-prefetch
+// variant is used (it needs the registers).
+struct CgPlan {
+    bool narrow, respf;
+    int slab, tiles_m, tiles_n;
+};
+
+static CgPlan cg_plan(int64_t M, int Cout, int batch, bool has_res, bool res_vec_ok)
+{
+    CgPlan p;
+    p.narrow = Cout <= 64 || (Cout % 128 != 0 && Cout % 128 <= 64 && Cout < 512);
+    p.tiles_m = (int)emp_cdiv(M, CG_BM);
+    p.tiles_n = (int)emp_cdiv(Cout, p.narrow ? 64 : 128);
+    p.respf = has_res && res_vec_ok && Cout % (p.narrow ? 64 : 128) == 0;
+    static const char *force = getenv("EMP_CONV_BK");          // experiments only: "16" / "32"
+    const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n * batch;
+    p.slab = blocks > 512 ? 16 : 32;
+    if (force && force[0] == '1') p.slab = 16;
+    if (force && force[0] == '3') p.slab = 32;
+    if (p.respf) p.slab = 32;
+    return p;
+}
+
+extern "C" int emp_conv_k_slab(int64_t M, int Cout, int batch, int has_residual)
+{
+    return cg_plan(M, Cout, batch, has_residual != 0, true).slab;
 }
 
 extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
@@ -363,23 +416,23 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     g.stride = stride; g.pad = pad; g.dil = dil; g.relu = relu;
     g.M = (int64_t)N * OH * OW; g.out_ps = out_pixel_stride; g.res_ps = res_pixel_stride;
     g.x_bs = g.w_bs = g.out_bs = 0; g.tiles = nullptr;
-    const int64_t tiles_m = emp_cdiv(g.M, CG_BM);
-    const bool narrow = Cout <= 64 || (Cout % 128 != 0 && Cout % 128 <= 64 && Cout < 512);
-    g.tiles_n = (int)emp_cdiv(Cout, narrow ? 64 : 128);
-    EMP_REQUIRE(tiles_m * g.tiles_n < (1LL << 28), "conv: too many tiles");
-    g.tiles_m = (int)tiles_m;
+    const bool res_vec_ok = (res_pixel_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
+    const CgPlan pl = cg_plan(g.M, Cout, 1, residual != nullptr, res_vec_ok);
+    const bool narrow = pl.narrow, respf = pl.respf, bk16 = pl.slab == 16;
+    EMP_REQUIRE((int64_t)pl.tiles_m * pl.tiles_n < (1LL << 28), "conv: too many tiles");
+    g.tiles_m = pl.tiles_m;
+    g.tiles_n = pl.tiles_n;
     const int T = g.tiles_m * g.tiles_n;
     const int grid = 8 * ((T + 7) / 8);
-    // residual prefetch: needs the vector path for every thread of every tile
-    const bool respf = residual && Cout % (narrow ? 64 : 128) == 0 && (res_pixel_stride & 3) == 0 &&
-                       (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
+#define CG_GO(NT_, RES_, BK_) hipLaunchKernelGGL((conv_igemm_f32_kernel<NT_, 0, RES_, BK_>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g)
     if (narrow) {
-        if (respf) hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0, true>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
-        else hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+        if (respf) CG_GO(1, true, 32);
+        else { if (bk16) CG_GO(1, false, 16); else CG_GO(1, false, 32); }
     } else {
-        if (respf) hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, true>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
-        else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+        if (respf) CG_GO(2, true, 32);
+        else { if (bk16) CG_GO(2, false, 16); else CG_GO(2, false, 32); }
     }
+#undef CG_GO
     EMP_CHECK_LAUNCH("emp_conv_bn_act_nhwc");
     return EMP_OK;
 }
@@ -509,13 +562,19 @@ extern "C" int emp_gemm_nt_batched(const float *A, const float *B, int batch, in
     g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
     g.M = M; g.out_ps = N; g.res_ps = N;
     g.x_bs = M * K; g.w_bs = (int64_t)N * K; g.out_bs = M * N; g.tiles = nullptr;
-    const bool narrow = N <= 64;
-    g.tiles_m = (int)emp_cdiv(M, CG_BM);
-    g.tiles_n = (int)emp_cdiv(N, narrow ? 64 : 128);
+    const CgPlan pl = cg_plan(M, N, batch, false, true);
+    const bool narrow = pl.narrow, bk16 = pl.slab == 16;
+    g.tiles_m = pl.tiles_m;
+    g.tiles_n = pl.tiles_n;
     const int T = g.tiles_m * g.tiles_n;
     dim3 grid(8 * ((T + 7) / 8), batch);
-    if (narrow) hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
-    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+    if (narrow) {
+        if (bk16) hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0, false, 16>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+        else hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0, false, 32>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+    } else {
+        if (bk16) hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, false, 16>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+        else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, false, 32>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+    }
     EMP_CHECK_LAUNCH("emp_gemm_nt_batched");
     return EMP_OK;
 }

@@ -97,12 +97,15 @@ int emp_upsample_bilinear(const float *x, int N, int C, int h, int w, const int6
  * out[p, co] = act(acc[p, co] * scale[co] + shift[co] + residual[p, co]); scale / shift / residual optional (NULL),
  * act = ReLU if relu != 0; acc = sum over taps (ky, kx) and input channels of x[n, oy*stride - pad + ky*dil,
  * ox*stride - pad + kx*dil, c] * w_okkc[co, ky, kx, c], evaluated as ONE fp32 fma chain from +0 (the MFMA is
- * bit-for-bit an fmaf chain): taps in raster order; per tap, slabs of 32 channels ascending; per slab the order
- * c, c + 16 for c = 0..15; taps outside the image enter as x = 0.  The epilogue's multiply and adds are separate
+ * bit-for-bit an fmaf chain): taps in raster order; per tap, slabs of S channels ascending; per slab the order
+ * c, c + S/2 for c = 0..S/2-1; taps outside the image enter as x = 0.  S = emp_conv_k_slab(M = N*OH*OW,
+ * Cout, 1, residual != NULL): 16 (three resident blocks per CU) when the launch has more than 512 blocks and does
+ * not use the residual-prefetch variant, else 32.  The epilogue's multiply and adds are separate
  * fp32 roundings, as in emp_bn_act_nhwc.
  * x: (N, H, W, Cin), Cin % 32 == 0; w_okkc: (Cout, KH, KW, Cin) (the Conv2d weight permuted); residual and out
  * are addressed as base + pixel * pixel_stride + co (stride 0 means Cout), so out may be a channel slice of a
  * wider NHWC concat buffer.  x and w 16-byte aligned; out must not alias x.                                    */
+int emp_conv_k_slab(int64_t M, int Cout, int batch, int has_residual);
 int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
                          const float *residual, int64_t res_pixel_stride, int relu, int N, int H, int W,
                          int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float *out,
@@ -119,7 +122,7 @@ int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale
  *    0 1 0 -1], evaluated as: columns first (t_a0 = d_a0 - d_a2, t_a1 = d_a1 + d_a2, t_a2 = d_a2 - d_a1,
  *    t_a3 = d_a1 - d_a3), then the same combination over rows.  x (N,H,W,C) fp32, V (16, T, C).
  * 2. emp_gemm_nt_batched: C[b] (M, N) = A[b] (M, K) * B[b] (N, K)^T for b < batch, on the fp32 matrix cores with
- *    the fma-chain order of emp_conv_bn_act_nhwc (slabs of 32, order c, c+16).  Here M = T, K = Cin, N = Cout,
+ *    the fma-chain order of emp_conv_bn_act_nhwc (slabs of S = emp_conv_k_slab(M, N, batch, 0)).  Here M = T, K = Cin, N = Cout,
  *    batch = 16, B = the transformed filters U[p, co, c] = (G g G^T)[u, v] prepared by the host.
  * 3. emp_wino_output_transform: Y = A^T M A per tile, A^T = [1 1 1 0; 0 1 -1 -1], rows first
  *    (s_0 = (m_0 + m_1) + m_2, s_1 = (m_1 - m_2) - m_3), then columns likewise; then the epilogue of

@@ -219,10 +219,11 @@ void emp_oracle_dwconv_nhwc(const float *x, const float *w_kkc, const float *bia
  * empanada/models/encoders/resnet.py:66-82,110-128; blocks.py:121-171).  The reference leaves the summation order
  * to the backend; this restatement fixes it to the order include/emp_hip.h (D4) documents for the MFMA kernel:
  * one fmaf chain from +0 over filter taps in raster order, per tap over slabs of 32 input channels, per slab in
- * the order c, c+16 for c = 0..15; taps outside the image enter as 0.  w: (Cout, KH, KW, Cin). */
+ * the order c, c + slab/2 for c = 0..slab/2-1 (slab = 32 or 16: emp_conv_k_slab); taps outside the image enter
+ * as 0.  w: (Cout, KH, KW, Cin). */
 void emp_oracle_conv_bn_act_nhwc(const float *x, const float *w, const float *scale, const float *shift,
                                  const float *res, int relu, int N, int H, int W, int Cin, int Cout, int KH,
-                                 int KW, int stride, int pad, int dil, float *out)
+                                 int KW, int stride, int pad, int dil, int slab, float *out)
 {
     const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
     const int OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
@@ -238,10 +239,10 @@ void emp_oracle_conv_bn_act_nhwc(const float *x, const float *w, const float *sc
                             const int in = iy >= 0 && iy < H && ix >= 0 && ix < W;
                             const float *xp = in ? x + (((int64_t)n * H + iy) * W + ix) * Cin : 0;
                             const float *wp = w + (((int64_t)co * KH + ky) * KW + kx) * Cin;
-                            for (int c0 = 0; c0 < Cin; c0 += 32)
-                                for (int j = 0; j < 16; ++j) {
+                            for (int c0 = 0; c0 < Cin; c0 += slab)
+                                for (int j = 0; j < slab / 2; ++j) {
                                     acc = fmaf(in ? xp[c0 + j] : 0.0f, wp[c0 + j], acc);
-                                    acc = fmaf(in ? xp[c0 + 16 + j] : 0.0f, wp[c0 + 16 + j], acc);
+                                    acc = fmaf(in ? xp[c0 + slab / 2 + j] : 0.0f, wp[c0 + slab / 2 + j], acc);
                                 }
                         }
                     float v = acc;

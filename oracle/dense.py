@@ -57,9 +57,11 @@ def upsample_bilinear(x, size):
     return ((ly0c * top).astype(np.float32) + (lyc * bot).astype(np.float32)).astype(np.float32)
 
 
-def conv_bn_act_nhwc(x_nhwc, w_okkc, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, dil=1):
+def conv_bn_act_nhwc(x_nhwc, w_okkc, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, dil=1,
+                     slab=32):
     """x (N,H,W,Cin), w (Cout,KH,KW,Cin), per-channel scale/shift, residual (N,OH,OW,Cout) -> (N,OH,OW,Cout),
-    all fp32; summation order of include/emp_hip.h (D4).  Plain C (oracle/c/oracle_kernels.c)."""
+    all fp32; summation order of include/emp_hip.h (D4) for the K-slab the kernel uses (emp_conv_k_slab).  Plain C
+    (oracle/c/oracle_kernels.c)."""
     x = np.ascontiguousarray(x_nhwc, dtype=np.float32)
     w = np.ascontiguousarray(w_okkc, dtype=np.float32)
     N, H, W, Cin = x.shape
@@ -78,7 +80,7 @@ def conv_bn_act_nhwc(x_nhwc, w_okkc, scale=None, shift=None, residual=None, relu
     keep = [ptr(a) for a in (scale, shift, residual)]
     lib().emp_oracle_conv_bn_act_nhwc(x.ctypes.data_as(f32p), w.ctypes.data_as(f32p), keep[0][1], keep[1][1],
                                       keep[2][1], int(bool(relu)), N, H, W, Cin, Cout, KH, KW, stride, pad, dil,
-                                      y.ctypes.data_as(f32p))
+                                      int(slab), y.ctypes.data_as(f32p))
     return y
 
 
@@ -97,7 +99,7 @@ def wino_filter_transform(w_oihw):
     return np.ascontiguousarray(np.stack(U, axis=0), dtype=np.float32)
 
 
-def wino_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=False):
+def wino_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=False, slab=32):
     """Winograd F(2x2,3x3) convolution exactly as include/emp_hip.h (D5) specifies it: input transform (numpy fp32,
     one rounding per add), 16 GEMMs through the C fma-chain oracle, output transform + epilogue.  Pinned against
     torch's conv2d within a stated tolerance in the GPU tests (the Winograd form is this framework's choice; the
@@ -121,7 +123,7 @@ def wino_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=Fa
         V[3 * 4 + v] = t[1][v] - t[3][v]
     M = np.empty((16, T, Cout), dtype=np.float32)
     for p in range(16):          # GEMM as a 1x1 convolution over a (1, 1, T, C) image
-        M[p] = conv_bn_act_nhwc(V[p][None, None], U[p][:, None, None, :])[0, 0]
+        M[p] = conv_bn_act_nhwc(V[p][None, None], U[p][:, None, None, :], slab=slab)[0, 0]
     m = [[M[a * 4 + b] for b in range(4)] for a in range(4)]
     s = [[(m[0][b] + m[1][b]) + m[2][b] for b in range(4)], [(m[1][b] - m[2][b]) - m[3][b] for b in range(4)]]
     out = np.zeros((N, H, W, Cout), dtype=np.float32)
@@ -216,7 +218,7 @@ def _at4(m):
             (m[1] + m[2]) + f(4) * (m[3] + m[4]), ((m[1] - m[2]) + f(8) * (m[3] - m[4])) + m[5]]
 
 
-def wino4_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=False):
+def wino4_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=False, slab=32):
     """Winograd F(4x4,3x3) exactly as include/emp_hip.h (D5b) specifies it (numpy fp32, one rounding per operation;
     GEMMs through the C fma-chain oracle)."""
     x = np.asarray(x_nhwc, dtype=np.float32)
@@ -236,7 +238,7 @@ def wino4_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=F
             V[u * 6 + v] = r[u]
     M = np.empty((36, T, Cout), dtype=np.float32)
     for p in range(36):
-        M[p] = conv_bn_act_nhwc(V[p][None, None], U[p][:, None, None, :])[0, 0]
+        M[p] = conv_bn_act_nhwc(V[p][None, None], U[p][:, None, None, :], slab=slab)[0, 0]
     s = [[None] * 6 for _ in range(4)]
     for b in range(6):
         r = _at4([M[a * 6 + b] for a in range(6)])

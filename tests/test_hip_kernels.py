@@ -478,6 +478,8 @@ def test_bn_act_into_channel_slice(hip):
     (1, 16, 14, 96, 64, 3, 2, 1, 1, False, False, True),       # stride 2
     (3, 7, 5, 32, 32, 1, 2, 0, 1, False, False, False),        # downsample-like, no epilogue
     (1, 10, 10, 64, 130, 3, 1, 6, 6, True, False, True),       # dilation wider than the image border
+    (8, 64, 64, 32, 320, 1, 1, 0, 1, False, True, True),       # > 512 blocks: the 16-wide K-slab variant
+    (8, 64, 64, 32, 320, 1, 1, 0, 1, True, True, True),        # same with a residual (not prefetchable: Cout % 128)
 ])
 def test_conv_bn_act_nhwc(hip, cfg):
     """emp_conv_bn_act_nhwc: bit-exact against the C oracle (same fma chain); within fp32 rounding of torch's
@@ -498,7 +500,8 @@ def test_conv_bn_act_nhwc(hip, cfg):
                                resd, relu, stride, pad, dil)
     exp = OD.conv_bn_act_nhwc(x.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), sc.numpy() if affine else None,
                               sh.numpy() if affine else None,
-                              res.permute(0, 2, 3, 1).numpy() if use_res else None, relu, stride, pad, dil)
+                              res.permute(0, 2, 3, 1).numpy() if use_res else None, relu, stride, pad, dil,
+                              slab=hip.conv_k_slab(ref.shape[0] * ref.shape[2] * ref.shape[3], Cout, 1, use_res))
     np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
     bound = torch.nn.functional.conv2d(x.abs(), w.abs(), None, stride=stride, padding=pad, dilation=dil)
     y = ref
@@ -543,9 +546,13 @@ def test_winograd_conv(hip, cfg):
     got = hip.wino_conv_bn_act(xd, U.cuda(), torch.from_numpy(tiles).cuda(), dil, sc.cuda(), sh.cuda(), True)
     unfused = hip.wino_conv_bn_act(xd, U.cuda(), torch.from_numpy(tiles).cuda(), dil, sc.cuda(), sh.cuda(), True,
                                    fused=False)
-    assert torch.equal(got, unfused)           # loader-fused input transform == separate transform kernel
-    exp = OD.wino_conv_bn_act(x.permute(0, 2, 3, 1).numpy(), w.numpy(), tiles, dil, sc.numpy(), sh.numpy(), True)
+    xn, wn = x.permute(0, 2, 3, 1).numpy(), w.numpy()
+    # loader-fused input transform (always 32-channel slabs) and separate transform + batched GEMM (slab by K)
+    exp = OD.wino_conv_bn_act(xn, wn, tiles, dil, sc.numpy(), sh.numpy(), True, slab=32)
     np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    slab = hip.conv_k_slab(len(tiles), Cout, 16)
+    exp_u = exp if slab == 32 else OD.wino_conv_bn_act(xn, wn, tiles, dil, sc.numpy(), sh.numpy(), True, slab=slab)
+    np.testing.assert_array_equal(unfused.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp_u.view(np.uint32))
     ref = torch.relu(torch.nn.functional.conv2d(x, w, None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1)
                      + sh.view(1, -1, 1, 1))
     bound = torch.nn.functional.conv2d(x.abs(), w.abs(), None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1)
@@ -614,7 +621,7 @@ def test_bn_relu_maxpool(hip, shape):
 
 
 @pytest.mark.parametrize('cfg', [(2, 9, 11, 64, 128, 1), (1, 12, 10, 32, 40, 2), (2, 13, 8, 64, 132, 6),
-                                 (1, 5, 7, 96, 64, 4), (2, 16, 16, 32, 256, 2)])
+                                 (1, 5, 7, 96, 64, 4), (2, 16, 16, 32, 256, 2), (8, 64, 64, 32, 64, 1)])
 def test_winograd4_conv(hip, cfg):
     """Winograd F(4x4,3x3) path (D5b): bit-exact against the oracle restatement; tiles partition the outputs; within
     the stated 2e-5 * sum|x||w| (+1e-6) of torch's conv2d + affine + relu."""
@@ -636,7 +643,8 @@ def test_winograd4_conv(hip, cfg):
     np.testing.assert_array_equal(U.numpy().view(np.uint32), OD.wino4_filter_transform(w.numpy()).view(np.uint32))
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     got = hip.wino4_conv_bn_act(xd, U.cuda(), torch.from_numpy(tiles).cuda(), dil, sc.cuda(), sh.cuda(), True)
-    exp = OD.wino4_conv_bn_act(x.permute(0, 2, 3, 1).numpy(), w.numpy(), tiles, dil, sc.numpy(), sh.numpy(), True)
+    exp = OD.wino4_conv_bn_act(x.permute(0, 2, 3, 1).numpy(), w.numpy(), tiles, dil, sc.numpy(), sh.numpy(), True,
+                               slab=hip.conv_k_slab(len(tiles), Cout, 36))
     np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
     ref = torch.relu(torch.nn.functional.conv2d(x, w, None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1)
                      + sh.view(1, -1, 1, 1))
