@@ -42,6 +42,8 @@ SIGNATURES = {
     'emp_gemm_nt_batched': (_I, [_P, _P, _I, _L, _I, _I, _P, _P]),
     'emp_wino4_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     'emp_wino4_output_transform': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _P]),
+    'emp_wino3_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
+    'emp_wino3_output_transform': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _P]),
     'emp_wino_gemm_fused': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _I, _P, _P]),
     'emp_wino_output_transform': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _P]),
     'emp_chain_class': (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _c.c_double, _c.c_double, _P, _P, _P, _P]),
@@ -519,7 +521,7 @@ def conv_bn_act_nhwc(x, w_okkc, scale=None, shift=None, residual=None, relu=Fals
 
 
 def wino_tiles(N, H, W, dil, m=2):
-    """(T, 3) int32 numpy table of Winograd F(m x m, 3x3) tiles (m = 2 or 4) for a 3x3 convolution with dilation
+    """(T, 3) int32 numpy table of Winograd F(m x m, 3x3) tiles (m = 2, 3 or 4) for a 3x3 convolution with dilation
     dil and padding dil: (n, y, x) of each tile's (m+2)x(m+2) patch origin, ordered (n, sub-grid row, sub-grid col,
     tile row, col)."""
     import numpy as np
@@ -659,3 +661,46 @@ def conv_k_slab(M, Cout, batch=1, has_residual=False):
     """K-slab (16 or 32) emp_conv_bn_act_nhwc / emp_gemm_nt_batched use for an (M x Cout) output, `batch` GEMMs per
     launch: fixes the summation order the oracle mirrors"""
     return int(load().emp_conv_k_slab(int(M), int(Cout), int(batch), int(bool(has_residual))))
+
+
+_WINO3_G = [[0.5, 0.0, 0.0], [-0.5, -0.5, -0.5], [-1.0 / 6, 1.0 / 6, -1.0 / 6], [1.0 / 6, 1.0 / 3, 2.0 / 3], [0.0, 0.0, 1.0]]
+
+
+def wino3_filter_transform(w_oihw):
+    """(Cout, Cin, 3, 3) -> U (25, Cout, Cin) = fp32(G g G^T) for F(3x3,3x3), elementwise fp64: rows first, each
+    row combination ((G[u][0]*g0 + G[u][1]*g1) + G[u][2]*g2), then columns likewise."""
+    g = w_oihw.detach().double().cpu()
+
+    def comb(a, b, c):
+        return [(G[0] * a + G[1] * b) + G[2] * c for G in _WINO3_G]
+
+    rows = comb(g[:, :, 0, :], g[:, :, 1, :], g[:, :, 2, :])
+    U = []
+    for r in rows:
+        U.extend(comb(r[:, :, 0], r[:, :, 1], r[:, :, 2]))
+    return torch.stack(U, dim=0).float().contiguous()
+
+
+def wino3_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, out=None):
+    """3x3 stride-1 convolution with padding == dilation through Winograd F(3x3,3x3) (emp_wino3_input_transform,
+    emp_gemm_nt_batched x 25, emp_wino3_output_transform); tiles from wino_tiles(..., m=3)."""
+    require_gpu()
+    N, Cin, H, W = x.shape
+    Cout = U.shape[1]
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    T = tiles_dev.shape[0]
+    V = torch.empty((25, T, Cin), dtype=torch.float32, device=x.device)
+    Mw = torch.empty((25, T, Cout), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    assert out.shape == (N, Cout, H, W) and out.stride(1) == 1
+    ops = out.stride(3)
+    assert out.stride(2) == W * ops and out.stride(0) == H * W * ops, "NHWC channel slice required"
+    st = stream()
+    call('emp_wino3_input_transform', x.data_ptr(), N, H, W, Cin, dil, _ptr(tiles_dev), T, _ptr(V), st,
+         alg_bytes=4 * (x.numel() + V.numel()))
+    call('emp_gemm_nt_batched', _ptr(V), _ptr(U), 25, T, Cout, Cin, _ptr(Mw), st,
+         alg_bytes=4 * (V.numel() + U.numel() + Mw.numel()), alg_flops=2 * 25 * T * Cout * Cin)
+    call('emp_wino3_output_transform', _ptr(Mw), _ptr(tiles_dev), T, N, H, W, Cout, dil, _ptr(scale), _ptr(shift),
+         int(bool(relu)), out.data_ptr(), ops, st, alg_bytes=4 * (Mw.numel() + N * Cout * H * W))
+    return out

@@ -774,3 +774,151 @@ extern "C" int emp_wino4_output_transform(const float *Mw, const int32_t *tiles,
     EMP_CHECK_LAUNCH("emp_wino4_output_transform");
     return EMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// D5c: Winograd F(3x3, 3x3) (points 0, 1, -1, 2, inf): 5x5 patches, 25 position GEMMs, 3x3 outputs per tile, 3.24x
+// fewer matrix-core FLOPs than the direct form.  It exists for the dilation-6 ASPP branch on 32-pixel maps: the
+// sub-grids have 5 or 6 rows, which two 3-row tiles cover almost exactly, while 4-row tiles waste half and 2-row
+// tiles need 3.  Transforms written generically: r[u] = left fold over the non-zero entries of row u (ascending
+// index) of c * d, every product and every sum one fp32 rounding.
+//   B^T = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1]      A^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 1]
+//   G   = [1/2 0 0; -1/2 -1/2 -1/2; -1/6 1/6 -1/6; 1/6 1/3 2/3; 0 0 1]  (host, fp64, rounded once)
+__device__ __forceinline__ void wino3_fold(const float (&c)[5], const v4 d[5], v4 &out)
+{
+    bool first = true;
+    out = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+        if (c[a] != 0.f) {
+            const v4 term = c[a] * d[a];
+            out = first ? term : out + term;
+            first = false;
+        }
+    }
+}
+
+__device__ __forceinline__ void wino3_bt(const v4 d[5], v4 r[5])
+{
+    constexpr float BT[5][5] = {{2, -1, -2, 1, 0}, {0, -2, -1, 1, 0}, {0, 2, -3, 1, 0}, {0, -1, 0, 1, 0}, {0, 2, -1, -2, 1}};
+#pragma unroll
+    for (int u = 0; u < 5; ++u) wino3_fold(BT[u], d, r[u]);
+}
+
+__device__ __forceinline__ void wino3_at(const v4 m[5], v4 s[3])
+{
+    constexpr float AT[3][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 0}, {0, 1, 1, 4, 1}};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) wino3_fold(AT[u], m, s[u]);
+}
+
+__global__ __launch_bounds__(256) void wino3_input_kernel(const float *__restrict__ x, const int32_t *__restrict__ tiles,
+                                                          int64_t T, int H, int W, int C4, int dil, float4 *__restrict__ V)
+{
+    const int64_t total = T * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const int64_t t = i / C4;
+        const int n = tiles[3 * t], by = tiles[3 * t + 1], bx = tiles[3 * t + 2];
+        const float4 *src = reinterpret_cast<const float4 *>(x) + (int64_t)n * H * W * C4 + c4;
+        v4 tt[5][5];
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            v4 d[5];
+            const int yy = by + a * dil;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                const int xx = bx + b * dil;
+                d[b] = {0.f, 0.f, 0.f, 0.f};
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) d[b] = ldv4(src + ((int64_t)yy * W + xx) * C4);
+            }
+            wino3_bt(d, tt[a]);
+        }
+        float4 *dst = V + t * C4 + c4;
+        const int64_t ps = T * C4;
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            v4 col[5], r[5];
+#pragma unroll
+            for (int a = 0; a < 5; ++a) col[a] = tt[a][v];
+            wino3_bt(col, r);
+#pragma unroll
+            for (int u = 0; u < 5; ++u) stv4(dst + (u * 5 + v) * ps, r[u]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino3_output_kernel(const float4 *__restrict__ Mw, const int32_t *__restrict__ tiles,
+                                                           int64_t T, int H, int W, int Co4, int dil,
+                                                           const float4 *__restrict__ scale, const float4 *__restrict__ shift,
+                                                           int relu, float *__restrict__ out, int64_t out_ps)
+{
+    const int64_t total = T * Co4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % Co4);
+        const int64_t t = i / Co4;
+        const int n = tiles[3 * t], oy = tiles[3 * t + 1] + dil, ox = tiles[3 * t + 2] + dil;
+        const float4 *src = Mw + t * Co4 + c4;
+        const int64_t ps = T * Co4;
+        v4 s[3][5];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            v4 m[5], r[3];
+#pragma unroll
+            for (int a = 0; a < 5; ++a) m[a] = ldv4(src + (a * 5 + b) * ps);
+            wino3_at(m, r);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) s[a][b] = r[a];
+        }
+        v4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (scale) sc = ldv4(scale + c4);
+        if (shift) sh = ldv4(shift + c4);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            v4 yv[3];
+            wino3_at(s[a], yv);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int yy = oy + a * dil, xx = ox + b * dil;
+                if (yy < H && xx < W) {
+                    v4 v = yv[b];
+                    if (scale) v = {__fmul_rn(v.x, sc.x), __fmul_rn(v.y, sc.y), __fmul_rn(v.z, sc.z), __fmul_rn(v.w, sc.w)};
+                    if (shift) v = v + sh;
+                    if (relu) v = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                    stv4(reinterpret_cast<float4 *>(out + (((int64_t)n * H + yy) * W + xx) * out_ps + 4 * c4), v);
+                }
+            }
+        }
+    }
+}
+
+extern "C" int emp_wino3_input_transform(const float *x, int N, int H, int W, int C, int dil, const int32_t *tiles,
+                                         int64_t T, float *V, void *stream)
+{
+    EMP_REQUIRE(x && tiles && V, "wino3_input: null pointer");
+    EMP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && dil >= 1 && T >= 0, "wino3_input: bad shape");
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(V)) & 15) == 0, "wino3_input: alignment");
+    if (T == 0) return EMP_OK;
+    hipLaunchKernelGGL(wino3_input_kernel, dim3(emp_grid(T * (C / 4), 256, 16384)), dim3(256), 0, emp_stream(stream), x,
+                       tiles, T, H, W, C / 4, dil, reinterpret_cast<float4 *>(V));
+    EMP_CHECK_LAUNCH("emp_wino3_input_transform");
+    return EMP_OK;
+}
+
+extern "C" int emp_wino3_output_transform(const float *Mw, const int32_t *tiles, int64_t T, int N, int H, int W,
+                                          int Cout, int dil, const float *scale, const float *shift, int relu,
+                                          float *out, int64_t out_pixel_stride, void *stream)
+{
+    EMP_REQUIRE(Mw && tiles && out, "wino3_output: null pointer");
+    EMP_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0 && dil >= 1 && T >= 0, "wino3_output: bad shape");
+    if (out_pixel_stride == 0) out_pixel_stride = Cout;
+    EMP_REQUIRE(out_pixel_stride >= Cout && out_pixel_stride % 4 == 0, "wino3_output: bad pixel stride");
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(Mw) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(scale) |
+                  reinterpret_cast<uintptr_t>(shift)) & 15) == 0, "wino3_output: alignment");
+    if (T == 0) return EMP_OK;
+    hipLaunchKernelGGL(wino3_output_kernel, dim3(emp_grid(T * (Cout / 4), 256, 16384)), dim3(256), 0, emp_stream(stream),
+                       reinterpret_cast<const float4 *>(Mw), tiles, T, H, W, Cout / 4, dil,
+                       reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift), relu, out,
+                       out_pixel_stride);
+    EMP_CHECK_LAUNCH("emp_wino3_output_transform");
+    return EMP_OK;
+}

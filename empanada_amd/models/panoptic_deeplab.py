@@ -138,6 +138,7 @@ class FusedConvBNAct(nn.Module):
                  emp_wino_output_transform
       'wino4'  : Winograd F(4x4,3x3), 36 GEMMs, 4x fewer matrix-core FLOPs; rounding error about 10x the direct
                  form's (emp_wino4_input_transform / emp_gemm_nt_batched / emp_wino4_output_transform)
+      'wino3'  : Winograd F(3x3,3x3), 25 GEMMs (for sub-grids of 5-6 rows: the dilation-6 ASPP branch)
       'wino_sep': the same with V materialised -- emp_wino_input_transform / emp_gemm_nt_batched /
                  emp_wino_output_transform (less L2 traffic per matrix-core FLOP; wins when Cin is large)
     tune_fused_convs() times the candidates on the layer's real shape and keeps the fastest."""
@@ -151,6 +152,7 @@ class FusedConvBNAct(nn.Module):
         self._w_okkc = None
         self._U = None
         self._U4 = None
+        self._U3 = None
         self._tiles = {}
 
     def candidates(self, has_residual):
@@ -163,7 +165,7 @@ class FusedConvBNAct(nn.Module):
             out.append('direct')
             if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == c.dilation and c.out_channels % 4 == 0
                     and not has_residual):
-                out.extend(['wino', 'wino_sep', 'wino4'])
+                out.extend(['wino', 'wino_sep', 'wino4', 'wino3'])
         return out
 
     def _prepare(self, impl):
@@ -174,6 +176,8 @@ class FusedConvBNAct(nn.Module):
             self._U = _hip.wino_filter_transform(self.conv.weight.detach())
         if impl == 'wino4' and self._U4 is None:
             self._U4 = _hip.wino4_filter_transform(self.conv.weight.detach()).to(self.conv.weight.device)
+        if impl == 'wino3' and self._U3 is None:
+            self._U3 = _hip.wino3_filter_transform(self.conv.weight.detach()).to(self.conv.weight.device)
 
     def release(self, keep):
         if keep != 'direct':
@@ -182,7 +186,9 @@ class FusedConvBNAct(nn.Module):
             self._U = None
         if keep != 'wino4':
             self._U4 = None
-        if keep not in ('wino', 'wino_sep', 'wino4'):
+        if keep != 'wino3':
+            self._U3 = None
+        if keep not in ('wino', 'wino_sep', 'wino4', 'wino3'):
             self._tiles = {}
 
     def forward(self, x, residual=None, out=None):
@@ -201,10 +207,13 @@ class FusedConvBNAct(nn.Module):
             return _hip.conv_bn_act_nhwc(x, self._w_okkc, self.bn.scale, self.bn.shift, residual, self.bn.relu,
                                          c.stride[0], c.padding[0], c.dilation[0], out)
         assert residual is None
-        m = 4 if impl == 'wino4' else 2
+        m = {'wino4': 4, 'wino3': 3}.get(impl, 2)
         key = (x.shape[0], x.shape[2], x.shape[3], m)
         if key not in self._tiles:
             self._tiles[key] = torch.from_numpy(_hip.wino_tiles(key[0], key[1], key[2], c.dilation[0], m)).to(x.device)
+        if impl == 'wino3':
+            return _hip.wino3_conv_bn_act(x, self._U3, self._tiles[key], c.dilation[0], self.bn.scale, self.bn.shift,
+                                          self.bn.relu, out)
         if impl == 'wino4':
             return _hip.wino4_conv_bn_act(x, self._U4, self._tiles[key], c.dilation[0], self.bn.scale, self.bn.shift,
                                           self.bn.relu, out)

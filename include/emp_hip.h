@@ -158,6 +158,19 @@ int emp_wino4_output_transform(const float *Mw, const int32_t *tiles, int64_t T,
                                int Cout, int dil, const float *scale, const float *shift, int relu,
                                float *out, int64_t out_pixel_stride, void *stream);
 
+/* ---- D5c: Winograd F(3x3, 3x3) (points 0, 1, -1, 2, inf): 5x5 patches, 25 positions, 3x3 outputs per tile -----
+ * tiles as in D5 with outputs (y + d + a*d, x + d + b*d), a, b in 0..2.  Transforms: r[u] = left fold, over the
+ * non-zero entries c of row u in ascending index, of fl(c * d[a]) with fp32 adds (columns first, then rows for
+ * the input; rows first, then columns for the output):
+ *   B^T = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1],  A^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 1].
+ * V (25, T, C), p = 5u + v; GEMMs: emp_gemm_nt_batched, batch 25, U (25, Cout, Cin) = fp32(G g G^T in fp64),
+ * G = [1/2 0 0; -1/2 -1/2 -1/2; -1/6 1/6 -1/6; 1/6 1/3 2/3; 0 0 1].  Stated tolerance as D5b.                    */
+int emp_wino3_input_transform(const float *x, int N, int H, int W, int C, int dil, const int32_t *tiles,
+                              int64_t T, float *V, void *stream);
+int emp_wino3_output_transform(const float *Mw, const int32_t *tiles, int64_t T, int N, int H, int W,
+                               int Cout, int dil, const float *scale, const float *shift, int relu,
+                               float *out, int64_t out_pixel_stride, void *stream);
+
 /* ---- D6: 1x1 convolution to 1..4 output channels on NHWC fp32 activations (last layer of every head) ----
  * replaces the final nn.Conv2d(nin, n_classes, 1, bias=True) of PanopticDeepLabHead   empanada/models/heads.py:9-19
  * out[n, co, r] = bias[co] + sum_c x[n*HW + r, c] * w[co, c]; evaluated per wave lane l as an fp32 fma chain from +0

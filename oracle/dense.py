@@ -259,3 +259,76 @@ def wino4_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=F
             ok = (yy < H) & (xx < W)
             out[tiles[ok, 0], yy[ok], xx[ok]] = v[ok]
     return out
+
+
+_W3_BT = [[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]]
+_W3_AT = [[1, 1, 1, 1, 0], [0, 1, -1, 2, 0], [0, 1, 1, 4, 1]]
+_W3_G = [[0.5, 0.0, 0.0], [-0.5, -0.5, -0.5], [-1.0 / 6, 1.0 / 6, -1.0 / 6], [1.0 / 6, 1.0 / 3, 2.0 / 3], [0.0, 0.0, 1.0]]
+
+
+def _fold(mat, d):
+    """r[u] = left fold over the non-zero entries of row u of fl(c * d[a]), fp32"""
+    out = []
+    for row in mat:
+        acc = None
+        for c, v in zip(row, d):
+            if c != 0:
+                term = (np.float32(c) * v).astype(np.float32)
+                acc = term if acc is None else (acc + term).astype(np.float32)
+        out.append(acc)
+    return out
+
+
+def wino3_filter_transform(w_oihw):
+    g = np.asarray(w_oihw, dtype=np.float64)
+
+    def comb(a, b, c):
+        return [(G[0] * a + G[1] * b) + G[2] * c for G in _W3_G]
+
+    rows = comb(g[:, :, 0, :], g[:, :, 1, :], g[:, :, 2, :])
+    U = []
+    for r in rows:
+        U.extend(comb(r[:, :, 0], r[:, :, 1], r[:, :, 2]))
+    return np.ascontiguousarray(np.stack(U, axis=0).astype(np.float32))
+
+
+def wino3_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=False, slab=32):
+    """Winograd F(3x3,3x3) exactly as include/emp_hip.h (D5c) specifies it."""
+    x = np.asarray(x_nhwc, dtype=np.float32)
+    N, H, W, C = x.shape
+    U = wino3_filter_transform(w_oihw)
+    Cout = U.shape[1]
+    T = len(tiles)
+    off = 4 * dil + 8
+    xp = np.zeros((N, H + 2 * off, W + 2 * off, C), dtype=np.float32)
+    xp[:, off:off + H, off:off + W] = x
+    n, by, bx = tiles[:, 0], tiles[:, 1] + off, tiles[:, 2] + off
+    tt = [_fold(_W3_BT, [xp[n, by + a * dil, bx + b * dil] for b in range(5)]) for a in range(5)]
+    V = np.empty((25, T, C), dtype=np.float32)
+    for v in range(5):
+        r = _fold(_W3_BT, [tt[a][v] for a in range(5)])
+        for u in range(5):
+            V[u * 5 + v] = r[u]
+    M = np.empty((25, T, Cout), dtype=np.float32)
+    for p in range(25):
+        M[p] = conv_bn_act_nhwc(V[p][None, None], U[p][:, None, None, :], slab=slab)[0, 0]
+    s = [[None] * 5 for _ in range(3)]
+    for b in range(5):
+        r = _fold(_W3_AT, [M[a * 5 + b] for a in range(5)])
+        for a in range(3):
+            s[a][b] = r[a]
+    out = np.zeros((N, H, W, Cout), dtype=np.float32)
+    for a in range(3):
+        yv = _fold(_W3_AT, s[a])
+        for b in range(3):
+            v = yv[b]
+            if scale is not None:
+                v = (v * np.asarray(scale, dtype=np.float32)).astype(np.float32)
+            if shift is not None:
+                v = (v + np.asarray(shift, dtype=np.float32)).astype(np.float32)
+            if relu:
+                v = np.maximum(v, np.float32(0))
+            yy, xx = tiles[:, 1] + dil + a * dil, tiles[:, 2] + dil + b * dil
+            ok = (yy < H) & (xx < W)
+            out[tiles[ok, 0], yy[ok], xx[ok]] = v[ok]
+    return out

@@ -650,3 +650,35 @@ def test_winograd4_conv(hip, cfg):
                      + sh.view(1, -1, 1, 1))
     bound = torch.nn.functional.conv2d(x.abs(), w.abs(), None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1)
     assert torch.all((got.cpu() - ref).abs() <= 2e-5 * bound + 1e-6)
+
+
+@pytest.mark.parametrize('cfg', [(2, 9, 11, 64, 128, 1), (1, 12, 10, 32, 40, 2), (2, 32, 32, 32, 64, 6),
+                                 (1, 5, 7, 96, 64, 4)])
+def test_winograd3_conv(hip, cfg):
+    """Winograd F(3x3,3x3) path (D5c): bit-exact against the oracle restatement; tiles partition the outputs; within
+    2e-5 * sum|x||w| (+1e-6) of torch's conv2d + affine + relu."""
+    from oracle import dense as OD
+    N, H, W, Cin, Cout, dil = cfg
+    g = torch.Generator().manual_seed(Cin + Cout + dil + H + 3)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / (Cin * 9) ** 0.5)
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    tiles = hip.wino_tiles(N, H, W, dil, m=3)
+    seen = np.zeros((N, H, W), dtype=np.int32)
+    for a in range(3):
+        for b in range(3):
+            yy, xx = tiles[:, 1] + dil + a * dil, tiles[:, 2] + dil + b * dil
+            ok = (yy < H) & (xx < W)
+            np.add.at(seen, (tiles[ok, 0], yy[ok], xx[ok]), 1)
+    assert np.all(seen == 1)
+    U = hip.wino3_filter_transform(w)
+    np.testing.assert_array_equal(U.numpy().view(np.uint32), OD.wino3_filter_transform(w.numpy()).view(np.uint32))
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    got = hip.wino3_conv_bn_act(xd, U.cuda(), torch.from_numpy(tiles).cuda(), dil, sc.cuda(), sh.cuda(), True)
+    exp = OD.wino3_conv_bn_act(x.permute(0, 2, 3, 1).numpy(), w.numpy(), tiles, dil, sc.numpy(), sh.numpy(), True,
+                               slab=hip.conv_k_slab(len(tiles), Cout, 25))
+    np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    ref = torch.relu(torch.nn.functional.conv2d(x, w, None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1)
+                     + sh.view(1, -1, 1, 1))
+    bound = torch.nn.functional.conv2d(x.abs(), w.abs(), None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1)
+    assert torch.all((got.cpu() - ref).abs() <= 2e-5 * bound + 1e-6)

@@ -273,7 +273,7 @@ def test_model_forward_matches_cpu_within_tolerance():
         assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (k, err, scale)
 
 
-@pytest.mark.parametrize('force', ['direct', 'wino', 'wino_sep', 'wino4', 'tuned'])
+@pytest.mark.parametrize('force', ['direct', 'wino', 'wino_sep', 'wino4', 'wino3', 'tuned'])
 def test_model_forward_with_hip_convolutions(force):
     """D4 / D5 inside the model: every conv + BN call site forced onto the implicit-GEMM kernel, onto Winograd
     where it applies, or left to the tuner -- same tolerance against the host module as the MIOpen path."""

@@ -84,6 +84,10 @@ for name, H, Cin, Cout, k, s, p, d, res in SHAPES:
             return _hip.wino4_conv_bn_act(x, U4, tiles4, d, sc, sh, True)
 
         w4_ms = timeit(wino4)
+        tiles3 = torch.from_numpy(_hip.wino_tiles(B, H, H, d, 3)).cuda()
+        U3 = _hip.wino3_filter_transform(w).cuda()
+        w3_ms = timeit(lambda: _hip.wino3_conv_bn_act(x, U3, tiles3, d, sc, sh, True))
+        w3err = (ref() - _hip.wino3_conv_bn_act(x, U3, tiles3, d, sc, sh, True)).abs().max().item()
         w4err = (ref() - wino4()).abs().max().item()
         _hip.PROFILE = {}
         wino()
@@ -105,5 +109,6 @@ for name, H, Cin, Cout, k, s, p, d, res in SHAPES:
         parts4 = {kk: round(v[0][0].elapsed_time(v[0][1]), 3) for kk, v in _hip.PROFILE.items()}
         _hip.PROFILE = None
         print(f"{'   winograd F(4,3)':34s} {w4_ms:12.3f}  speedup vs miopen+bn {a / w4_ms:.2f}  parts {parts4}  maxerr {w4err:.2e}")
-        tot_b += min(a, b, wino_ms, w4_ms) - min(a, b)
+        print(f"{'   winograd F(3,3)':34s} {w3_ms:12.3f}  speedup vs miopen+bn {a / w3_ms:.2f}  maxerr {w3err:.2e}")
+        tot_b += min(a, b, wino_ms, w4_ms, w3_ms) - min(a, b)
 print(f"sum miopen+bn {tot_a:.2f} ms; sum best-of {tot_b:.2f} ms")
