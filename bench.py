@@ -203,10 +203,13 @@ def build_inputs_ortho(S, device, rank=0, world=1):
     return stacks, heads, int(cls.shape[0] - 1), lo
 
 
-def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages):
+def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages, first=None, prefetch_next=False):
     """One pass of BASELINE configs[2]: three slice-sharded stacks (xy, xz, yz) -> trackers stitched on rank 0 ->
     filters -> instance consensus -> filters -> labelled volume in pinned host memory
-    (scripts/pdl_inference3d.py:110-233 in orthoplane mode)."""
+    (scripts/pdl_inference3d.py:110-233 in orthoplane mode).
+    Consecutive passes are software-pipelined like the stack mode: with prefetch_next the xy forward of the NEXT pass
+    is queued as soon as this pass's yz tables are on the host, so the tail (yz tracking, consensus, fill, D2H; post
+    stream + host) runs under it; the caller hands the returned (checksum, event) back as `first`."""
     from empanada_amd.inference import sharded
     trackers = {}
     chk = 0
@@ -216,10 +219,14 @@ def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages):
     # (Queuing all three forwards up front does not work: ~14k launches exceed the HIP queue and the host blocks.)
     post = pipe.post_stream
     planes = ('xy', 'xz', 'yz')
-    prob, c = pipe.forward(*stacks['xy'])
+    if first is None:
+        prob, c = pipe.forward(*stacks['xy'])
+        ev = torch.cuda.Event()
+        ev.record()
+    else:
+        c, ev = first
     chk = chk + c
-    ev = torch.cuda.Event()
-    ev.record()
+    nxt = None
     with torch.cuda.stream(post):
         for i, axis in enumerate(planes):
             t0 = time.perf_counter()
@@ -235,6 +242,12 @@ def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages):
                     chk = chk + c
                     ev = torch.cuda.Event()
                     ev.record()
+            elif prefetch_next:
+                with torch.cuda.stream(torch.cuda.default_stream()):
+                    prob, c2 = pipe.forward(*stacks['xy'])
+                    ev2 = torch.cuda.Event()
+                    ev2.record()
+                    nxt = (c2, ev2)
             t2 = time.perf_counter()
             trackers[axis] = sharded.finish_plane(table, host, pan.shape[0], axis, shape3d, slice0, [1],
                                                   ENGINE['thing_list'], ENGINE['label_divisor'], **MATCH)
@@ -243,7 +256,7 @@ def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages):
             stages[f'{axis}_tracking'] = stages.get(f'{axis}_tracking', 0) + time.perf_counter() - t2
         n_found = _orthoplane_finish(trackers, shape3d, host_out, stages)
     torch.cuda.current_stream().wait_stream(post)
-    return chk, n_found
+    return chk, n_found, nxt
 
 
 def _orthoplane_finish(trackers, shape3d, host_out, stages):
@@ -255,7 +268,7 @@ def _orthoplane_finish(trackers, shape3d, host_out, stages):
                                               FILTERS['min_size'], FILTERS['min_span'])
         t1 = time.perf_counter()
         host_out.copy_(vols[1].view(torch.int32), non_blocking=True)
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()          # the post stream only: a prefetched forward keeps running
         stages['consensus_and_fill'] = stages.get('consensus_and_fill', 0) + t1 - t0
         stages['to_host'] = stages.get('to_host', 0) + time.perf_counter() - t1
         n_found = len(cons[1].instances)
@@ -286,8 +299,10 @@ def main_orthoplane(args, device, rank, world):
     barrier()
     stages = {}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        chk, n_found = orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages)
+    first = None
+    for k in range(args.steps):
+        chk, n_found, first = orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages, first,
+                                              prefetch_next=(k + 1 < args.steps) and not args.no_pipeline)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
