@@ -78,6 +78,8 @@ def parse():
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--save-tune', default=None, help='write the tuned conv implementation per call site (json)')
     ap.add_argument('--load-tune', default=None, help='replay conv implementations from a --save-tune file')
+    ap.add_argument('--conv-impls', default=None,
+                    help='comma list restricting the tuner, e.g. miopen,direct (no Winograd forms)')
     ap.add_argument('--no-tune', action='store_true', help='keep MIOpen + epilogue pass for every convolution')
     ap.add_argument('--cpu-slices', type=int, default=96, help='slices of the same workload for the CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -116,6 +118,7 @@ class Pipeline:
         self.batch = args.batch
         self.timers = {}
         self.tuned = {}
+        self.conv_impls = args.conv_impls.split(',') if args.conv_impls else None
         self.post_stream = torch.cuda.Stream(device=device)
 
     @torch.no_grad()
@@ -137,7 +140,7 @@ class Pipeline:
             log(f'conv call sites loaded from {load}: {counts}')
             return
         x = torch.rand((self.batch, 1, size, size), device=self.device).contiguous(memory_format=torch.channels_last)
-        rep = tune_fused_convs(self.model, x)
+        rep = tune_fused_convs(self.model, x, allow=self.conv_impls)
         for _, (best, _) in rep.items():
             counts[best] = counts.get(best, 0) + 1
         self.tuned = counts

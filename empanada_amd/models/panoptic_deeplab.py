@@ -662,9 +662,12 @@ def pair_conv_bn(model):
 
 
 @torch.no_grad()
-def tune_fused_convs(model, example, reps=5, verbose=False):
+def tune_fused_convs(model, example, reps=5, verbose=False, allow=None):
     """Pick, per FusedConvBNAct call site, the fastest of its implementations on the shapes `example` produces
-    (isolated timing with HIP events).  Returns {module name: (chosen, {impl: ms})}."""
+    (isolated timing with HIP events).  `allow`: optional collection restricting the candidates (e.g.
+    ('miopen', 'direct') to keep every convolution in the direct form: the Winograd forms are fp32 too but round
+    differently -- F(2x2) about 2x, F(3x3) / F(4x4) about 10x the direct form's rounding error).
+    Returns {module name: (chosen, {impl: ms})}."""
     model(example)                                   # records the shapes (and lets MIOpen pick its kernels)
     report = {}
     for name, m in model.named_modules():
@@ -676,6 +679,8 @@ def tune_fused_convs(model, example, reps=5, verbose=False):
         res = torch.randn_like(m(x)) if has_res else None
         times = {}
         for impl in m.candidates(has_res):
+            if allow is not None and impl not in allow and impl != 'miopen':
+                continue
             m.impl = impl
             for _ in range(2):
                 m(x, res)
