@@ -36,6 +36,7 @@ SIGNATURES = {
     'emp_bn_act_nhwc': (_I, [_P, _P, _P, _P, _I, _L, _I, _P, _L, _P]),
     'emp_dwconv_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'emp_upsample_bilinear': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
+    'emp_conv_bn_act_proj_nhwc': (_I, [_P, _P, _P, _P, _I] + [_I] * 10 + [_P, _I, _P, _P, _L, _P]),
     'emp_conv_k_slab': (_I, [_L, _I, _I, _I]),
     'emp_conv_bn_act_nhwc': (_I, [_P, _P, _P, _P, _P, _L, _I] + [_I] * 10 + [_P, _L, _P]),
     'emp_wino_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
@@ -704,3 +705,26 @@ def wino3_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, 
     call('emp_wino3_output_transform', _ptr(Mw), _ptr(tiles_dev), T, N, H, W, Cout, dil, _ptr(scale), _ptr(shift),
          int(bool(relu)), out.data_ptr(), ops, st, alg_bytes=4 * (Mw.numel() + N * Cout * H * W))
     return out
+
+
+def conv_bn_act_proj_nhwc(x, w_okkc, scale, shift, relu, proj_w, proj_b=None, stride=1, pad=0, dil=1, keep=False):
+    """Convolution + affine + ReLU whose epilogue also applies a following 1x1 convolution to <= 4 channels
+    (emp_conv_bn_act_proj_nhwc).  x (N,Cin,H,W) channels_last, w_okkc (Cout in {128, 256}, KH, KW, Cin), proj_w
+    (n, Cout), proj_b (n) or None.  Returns the planar (N, n, OH, OW) result (and the activation if keep)."""
+    require_gpu()
+    N, Cin, H, W = x.shape
+    Cout, KH, KW, _ = w_okkc.shape
+    n = proj_w.shape[0]
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    acc = torch.zeros((N, n, OH, OW), dtype=torch.float32, device=x.device)
+    act = (torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+           if keep else None)
+    call('emp_conv_bn_act_proj_nhwc', x.data_ptr(), _ptr(w_okkc), _ptr(scale), _ptr(shift), int(bool(relu)), N, H, W,
+         Cin, Cout, KH, KW, stride, pad, dil, _ptr(proj_w), n, _ptr(acc), act.data_ptr() if keep else None, 0,
+         stream(), alg_bytes=4 * (x.numel() + w_okkc.numel() + acc.numel() + (act.numel() if keep else 0)),
+         alg_flops=2 * N * OH * OW * Cout * (Cin * KH * KW + n))
+    if proj_b is not None:
+        acc += proj_b.view(1, -1, 1, 1)
+    return (acc, act) if keep else acc

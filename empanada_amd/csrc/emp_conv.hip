@@ -32,6 +32,10 @@ struct ConvGeom {
     int tiles_m, tiles_n;
     int64_t x_bs, w_bs, out_bs;      // blockIdx.y batches (Winograd positions): element strides of x, w, out
     const int32_t *tiles;            // MODE 1: (M, 3) Winograd tile table
+    const float *proj_w;             // PROJ: (proj_n, Cout) weights of a following 1x1 convolution to a few channels
+    float *proj_out;                 // PROJ: planar (N, proj_n, hw) accumulator, zeroed by the caller
+    int proj_n;
+    int64_t hw;                      // PROJ: pixels per image
 };
 
 // NT = 32-wide cout tiles per wave: block tile 128 x (64 * NT) (NT = 1 for layers with Cout <= 64)
@@ -46,7 +50,12 @@ struct ConvGeom {
 //        16: 32 MFMAs between barriers, 40 KiB of LDS and <= 168 VGPRs, 3 blocks per CU: the prologue / epilogue of
 //        one block (global latency, LDS staging, stores) hides behind the matrix work of two others -- better for
 //        short K loops.  Inside a slab the k-step j consumes channels j and BK/2 + j.
-template <int NT, int MODE, bool RESPF = false, int BK = 32>
+// PROJ:  the epilogue also feeds a following 1x1 convolution to a few channels (the heads' last layer): per row and
+//        output channel q, lane partial ((v0 w0 + v1 w1) + v2 w2) + v3 w3 over its 4 couts, parked in LDS and summed
+//        over the row's BN/4 lanes in ascending order, one atomicAdd per (row, q, cout tile) into a zeroed planar
+//        accumulator.  With at most two cout tiles the result does not depend on the order of the atomics
+//        (0 + a + b == 0 + b + a).  The activation itself need not be written (out == NULL).
+template <int NT, int MODE, bool RESPF = false, int BK = 32, bool PROJ = false>
 __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32_kernel(ConvGeom g)
 {
     constexpr int BN = 64 * NT;
@@ -325,9 +334,11 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
             const int lrow_c = crow + it * RPI;            // row inside the staged chunk
             const int row = rd * EPI_ROWS + lrow_c;        // row inside the block tile
             const int64_t p = m0 + row;
-            if (p < g.M) {
+            const bool valid = p < g.M;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
                 const float4 a4 = *reinterpret_cast<const float4 *>(&Cs[lrow_c * CLD + ccol]);
-                float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                v[0] = a4.x; v[1] = a4.y; v[2] = a4.z; v[3] = a4.w;
                 float rr[4] = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (RESPF) {
                     const float4 r4 = rpre[rd * NRR + it];
@@ -349,12 +360,43 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
                     if (g.res) v[e] = __fadd_rn(v[e], rr[e]);
                     if (g.relu) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (vec_ok) {
-                    *reinterpret_cast<float4 *>(g.out + p * g.out_ps + co) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
+                if (!PROJ || g.out) {
+                    if (vec_ok) {
+                        *reinterpret_cast<float4 *>(g.out + p * g.out_ps + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (co + e < g.Cout) g.out[p * g.out_ps + co + e] = v[e];
+                        for (int e = 0; e < 4; ++e)
+                            if (co + e < g.Cout) g.out[p * g.out_ps + co + e] = v[e];
+                    }
+                }
+            }
+            if constexpr (PROJ) {
+                // lane partials of the following 1x1 convolution, parked in the thread's own (already consumed)
+                // float4 slot of the staging tile: component q = output channel q
+                float ps[4] = {0.f, 0.f, 0.f, 0.f};
+                if (valid && co + 3 < g.Cout) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q < g.proj_n) {
+                            const float4 wq = *reinterpret_cast<const float4 *>(g.proj_w + (int64_t)q * g.Cout + co);
+                            ps[q] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(v[0], wq.x), __fmul_rn(v[1], wq.y)),
+                                                        __fmul_rn(v[2], wq.z)), __fmul_rn(v[3], wq.w));
+                        }
+                }
+                *reinterpret_cast<float4 *>(&Cs[lrow_c * CLD + ccol]) = make_float4(ps[0], ps[1], ps[2], ps[3]);
+            }
+        }
+        if constexpr (PROJ) {
+            __syncthreads();
+            for (int idx = tid; idx < EPI_ROWS * g.proj_n; idx += CG_THREADS) {
+                const int row_l = idx / g.proj_n, q = idx - row_l * g.proj_n;
+                const int64_t p = m0 + rd * EPI_ROWS + row_l;
+                if (p < g.M) {
+                    float t = Cs[row_l * CLD + q];
+#pragma unroll 8
+                    for (int j = 1; j < C4; ++j) t = __fadd_rn(t, Cs[row_l * CLD + 4 * j + q]);   // lanes in ascending order
+                    const int64_t img = p / g.hw;
+                    atomicAdd(g.proj_out + (img * g.proj_n + q) * g.hw + (p - img * g.hw), t);
                 }
             }
         }
@@ -415,7 +457,7 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KH = KH; g.KW = KW;
     g.stride = stride; g.pad = pad; g.dil = dil; g.relu = relu;
     g.M = (int64_t)N * OH * OW; g.out_ps = out_pixel_stride; g.res_ps = res_pixel_stride;
-    g.x_bs = g.w_bs = g.out_bs = 0; g.tiles = nullptr;
+    g.x_bs = g.w_bs = g.out_bs = 0; g.tiles = nullptr; g.proj_w = nullptr; g.proj_out = nullptr; g.proj_n = 0; g.hw = 1;
     const bool res_vec_ok = (res_pixel_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
     const CgPlan pl = cg_plan(g.M, Cout, 1, residual != nullptr, res_vec_ok);
     const bool narrow = pl.narrow, respf = pl.respf, bk16 = pl.slab == 16;
@@ -434,6 +476,42 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     }
 #undef CG_GO
     EMP_CHECK_LAUNCH("emp_conv_bn_act_nhwc");
+    return EMP_OK;
+}
+
+extern "C" int emp_conv_bn_act_proj_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
+                                         int relu, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                         int pad, int dil, const float *proj_w, int proj_n, float *proj_out,
+                                         float *out, int64_t out_pixel_stride, void *stream)
+{
+    EMP_REQUIRE(x && w_okkc && proj_w && proj_out, "conv_proj: null pointer");
+    EMP_REQUIRE(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cin % CG_BK == 0, "conv_proj: bad shape (Cin %% %d)", CG_BK);
+    EMP_REQUIRE(Cout == 128 || Cout == 256, "conv_proj: Cout %d must be 128 or 256 (at most two cout tiles)", Cout);
+    EMP_REQUIRE(proj_n >= 1 && proj_n <= 4, "conv_proj: proj_n %d not in 1..4", proj_n);
+    EMP_REQUIRE(KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7 && stride >= 1 && dil >= 1 && pad >= 0, "conv_proj: bad filter geometry");
+    const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+    const int OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    EMP_REQUIRE(OH > 0 && OW > 0, "conv_proj: empty output");
+    if (out_pixel_stride == 0) out_pixel_stride = Cout;
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_okkc) | reinterpret_cast<uintptr_t>(proj_w) |
+                  reinterpret_cast<uintptr_t>(out)) & 15) == 0 && (out_pixel_stride & 3) == 0, "conv_proj: alignment");
+    EMP_REQUIRE(out != x, "conv_proj: output cannot alias the input");
+    if (N == 0) return EMP_OK;
+    ConvGeom g;
+    g.x = x; g.w = w_okkc; g.scale = scale; g.shift = shift; g.res = nullptr; g.out = out;
+    g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KH = KH; g.KW = KW;
+    g.stride = stride; g.pad = pad; g.dil = dil; g.relu = relu;
+    g.M = (int64_t)N * OH * OW; g.out_ps = out_pixel_stride; g.res_ps = Cout;
+    g.x_bs = g.w_bs = g.out_bs = 0; g.tiles = nullptr;
+    g.proj_w = proj_w; g.proj_out = proj_out; g.proj_n = proj_n; g.hw = (int64_t)OH * OW;
+    const CgPlan pl = cg_plan(g.M, Cout, 1, false, true);
+    g.tiles_m = pl.tiles_m;
+    g.tiles_n = pl.tiles_n;
+    const int T = g.tiles_m * g.tiles_n;
+    const int grid = 8 * ((T + 7) / 8);
+    if (pl.slab == 16) hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, false, 16, true>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, false, 32, true>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+    EMP_CHECK_LAUNCH("emp_conv_bn_act_proj_nhwc");
     return EMP_OK;
 }
 
@@ -561,7 +639,7 @@ extern "C" int emp_gemm_nt_batched(const float *A, const float *B, int batch, in
     g.N = 1; g.H = 1; g.W = (int)M; g.Cin = K; g.OH = 1; g.OW = (int)M; g.Cout = N; g.KH = g.KW = 1;
     g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
     g.M = M; g.out_ps = N; g.res_ps = N;
-    g.x_bs = M * K; g.w_bs = (int64_t)N * K; g.out_bs = M * N; g.tiles = nullptr;
+    g.x_bs = M * K; g.w_bs = (int64_t)N * K; g.out_bs = M * N; g.tiles = nullptr; g.proj_w = nullptr; g.proj_out = nullptr; g.proj_n = 0; g.hw = 1;
     const CgPlan pl = cg_plan(M, N, batch, false, true);
     const bool narrow = pl.narrow, bk16 = pl.slab == 16;
     g.tiles_m = pl.tiles_m;
@@ -593,7 +671,7 @@ extern "C" int emp_wino_gemm_fused(const float *x, int N, int H, int W, int Cin,
     g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.OH = 1; g.OW = 1; g.Cout = Cout; g.KH = g.KW = 1;
     g.stride = 1; g.pad = 0; g.dil = dil; g.relu = 0;
     g.M = T; g.out_ps = Cout; g.res_ps = Cout;
-    g.x_bs = 0; g.w_bs = (int64_t)Cout * Cin; g.out_bs = T * Cout; g.tiles = tiles;
+    g.x_bs = 0; g.w_bs = (int64_t)Cout * Cin; g.out_bs = T * Cout; g.tiles = tiles; g.proj_w = nullptr; g.proj_out = nullptr; g.proj_n = 0; g.hw = 1;
     const bool narrow = Cout <= 64;
     g.tiles_m = (int)emp_cdiv(T, CG_BM);
     g.tiles_n = (int)emp_cdiv(Cout, narrow ? 64 : 128);

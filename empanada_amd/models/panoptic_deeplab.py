@@ -453,8 +453,24 @@ class PanopticDeepLabHead(nn.Module):
     def __init__(self, nin, n_classes):
         super().__init__()
         self.head = nn.Sequential(_sepconv_bn_act(nin, nin, 5), nn.Conv2d(nin, n_classes, 1, bias=True))
+        self.hip_ops = False
 
     def forward(self, x):
+        if self.hip_ops and x.is_cuda and x.dtype == torch.float32:
+            # depthwise -> [pointwise conv + BN + ReLU + last 1x1 conv] in one launch: the 256-channel activation
+            # between the last two layers is never written (emp_conv_bn_act_proj_nhwc)
+            sep = self.head[0][0]
+            site = sep.sepconv[1] if isinstance(sep, SeparableConv2d) else None
+            last = self.head[1]
+            if (isinstance(site, FusedConvBNAct) and site.impl == 'direct' and isinstance(last, PointwiseOutNHWC)
+                    and site.conv.out_channels in (128, 256) and site.conv.kernel_size == (1, 1)):
+                from .. import _hip
+                y = sep.sepconv[0](x)
+                if not y.is_contiguous(memory_format=torch.channels_last):
+                    y = y.contiguous(memory_format=torch.channels_last)
+                site._prepare('direct')
+                return _hip.conv_bn_act_proj_nhwc(y, site._w_okkc, site.bn.scale, site.bn.shift, site.bn.relu,
+                                                  last.w, last.b)
         return self.head(x)
 
 

@@ -111,6 +111,18 @@ int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale
                          int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float *out,
                          int64_t out_pixel_stride, void *stream);
 
+/* D4 + D6 in one launch: the convolution's epilogue also evaluates a following 1x1 convolution to proj_n <= 4
+ * channels (head = separable conv -> BN -> ReLU -> Conv2d(256, n, 1): heads.py:9-19), so the 256-channel activation
+ * is neither written nor re-read (out may be NULL).  proj_out (N, proj_n, OH*OW) planar, ZEROED by the caller;
+ * bias is the caller's to add.  Per output pixel and q: for each cout tile (128 wide) the 32 lanes of the row hold
+ * ((v0 w0 + v1 w1) + v2 w2) + v3 w3 over their 4 couts (products and sums separate fp32 roundings), summed over
+ * the lanes in ascending cout order (left fold), and the tile sums are added to proj_out with one atomicAdd each
+ * (Cout is 128 or 256: with at most two tiles the result is independent of their order).                      */
+int emp_conv_bn_act_proj_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
+                              int relu, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                              int pad, int dil, const float *proj_w, int proj_n, float *proj_out,
+                              float *out, int64_t out_pixel_stride, void *stream);
+
 /* ---- D5: Winograd F(2x2, 3x3) convolution in three calls (3x3, stride 1, padding == dilation) ---------
  * replaces the dilated 3x3 Conv2d -> BatchNorm2d -> ReLU of ASPP and of the dilated ResNet stage
  *          (empanada/models/decoders/aspp.py:22-46, encoders/resnet.py:110-128) where Cin is large.

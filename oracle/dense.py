@@ -332,3 +332,31 @@ def wino3_conv_bn_act(x_nhwc, w_oihw, tiles, dil, scale=None, shift=None, relu=F
             ok = (yy < H) & (xx < W)
             out[tiles[ok, 0], yy[ok], xx[ok]] = v[ok]
     return out
+
+
+def conv_bn_act_proj_nhwc(x_nhwc, w_okkc, scale, shift, relu, proj_w, proj_b=None, stride=1, pad=0, dil=1, slab=32):
+    """emp_conv_bn_act_proj_nhwc (emp_hip.h, D4 + D6): activation from the conv oracle, then per cout tile of 128 the
+    lane partials ((v0 w0 + v1 w1) + v2 w2) + v3 w3, their left fold over the 32 lanes, the sum of the (at most two) tiles
+    and the bias -- numpy fp32, one rounding per operation.  Returns planar (N, n, OH, OW)."""
+    y = conv_bn_act_nhwc(x_nhwc, w_okkc, scale, shift, None, relu, stride, pad, dil, slab)     # (N, OH, OW, Cout)
+    N, OH, OW, Cout = y.shape
+    pw = np.asarray(proj_w, dtype=np.float32)
+    n = pw.shape[0]
+    P = N * OH * OW
+    yf = y.reshape(P, Cout)
+    out = np.zeros((P, n), dtype=np.float32)
+    for q in range(n):
+        total = None
+        for t0 in range(0, Cout, 128):
+            v = yf[:, t0:t0 + 128].reshape(P, 32, 4)
+            w = pw[q, t0:t0 + 128].reshape(32, 4)
+            pr = (v * w[None]).astype(np.float32)
+            s = (((pr[:, :, 0] + pr[:, :, 1]).astype(np.float32) + pr[:, :, 2]).astype(np.float32) + pr[:, :, 3]).astype(np.float32)
+            acc = s[:, 0]
+            for j in range(1, 32):
+                acc = (acc + s[:, j]).astype(np.float32)
+            total = acc if total is None else (total + acc).astype(np.float32)
+        if proj_b is not None:
+            total = (total + np.float32(proj_b[q])).astype(np.float32)
+        out[:, q] = total
+    return np.ascontiguousarray(out.reshape(N, OH * OW, n).transpose(0, 2, 1)).reshape(N, n, OH, OW)

@@ -682,3 +682,34 @@ def test_winograd3_conv(hip, cfg):
                      + sh.view(1, -1, 1, 1))
     bound = torch.nn.functional.conv2d(x.abs(), w.abs(), None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1)
     assert torch.all((got.cpu() - ref).abs() <= 2e-5 * bound + 1e-6)
+
+
+@pytest.mark.parametrize('cfg', [(2, 9, 11, 64, 256, 1, 2), (1, 7, 5, 32, 128, 1, 1), (2, 8, 8, 64, 256, 3, 4),
+                                 (8, 64, 64, 32, 256, 1, 2)])
+def test_conv_bn_act_with_projection(hip, cfg):
+    """emp_conv_bn_act_proj_nhwc (head pointwise conv + BN + ReLU + last 1x1 conv in one launch): bit-exact against
+    the oracle restatement, deterministic across runs (atomics over at most two tiles), activation optional; within
+    1e-5 * (sum|x||w| * |scale| * sum|proj_w| ...) of the torch ops."""
+    from oracle import dense as OD
+    N, H, W, Cin, Cout, k, n = cfg
+    g = torch.Generator().manual_seed(Cin + Cout + k + n)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k) ** 0.5)
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    pw, pb = torch.randn(n, Cout, generator=g) * 0.1, torch.randn(n, generator=g)
+    w_okkc = w.permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    args = (xd, w_okkc.cuda(), sc.cuda(), sh.cuda(), True, pw.cuda(), pb.cuda(), 1, k // 2, 1)
+    got = hip.conv_bn_act_proj_nhwc(*args)
+    got2, act = hip.conv_bn_act_proj_nhwc(*args, keep=True)
+    assert torch.equal(got, got2) and torch.equal(got, hip.conv_bn_act_proj_nhwc(*args))
+    plain = hip.conv_bn_act_nhwc(xd, w_okkc.cuda(), sc.cuda(), sh.cuda(), None, True, 1, k // 2, 1)
+    assert torch.equal(act, plain)
+    M = N * H * W
+    exp = OD.conv_bn_act_proj_nhwc(x.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), sc.numpy(), sh.numpy(), True,
+                                   pw.numpy(), pb.numpy(), 1, k // 2, 1, slab=hip.conv_k_slab(M, Cout))
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    y = torch.relu(torch.nn.functional.conv2d(x, w, None, padding=k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ref = torch.nn.functional.conv2d(y, pw.view(n, Cout, 1, 1), pb)
+    bound = torch.nn.functional.conv2d(y.abs() + 1, pw.abs().view(n, Cout, 1, 1))
+    assert torch.all((got.cpu() - ref).abs() <= 1e-5 * bound + 1e-6)
