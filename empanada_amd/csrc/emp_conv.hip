@@ -38,6 +38,23 @@ struct ConvGeom {
     int64_t hw;                      // PROJ: pixels per image
 };
 
+// 64 floats of zeros: the source of rows that fall outside the problem (padding taps, rows past M, couts past Cout)
+// for the LDS-direct loader, which cannot mask data in flight
+__device__ __attribute__((aligned(16))) float cg_zero_page[64];
+
+// 16 bytes per lane from global memory straight into LDS (gfx950 global_load_lds_dwordx4): lane l's data lands at
+// lds_byte_addr + 16 * l whatever its source address.  Not tracked by the compiler: pair with cg_wait_vm.
+__device__ __forceinline__ void cg_glds16(const float *src, unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory", "m0");
+}
+
+template <int N>
+__device__ __forceinline__ void cg_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // NT = 32-wide cout tiles per wave: block tile 128 x (64 * NT) (NT = 1 for layers with Cout <= 64)
 // MODE 0: A rows are output pixels of a convolution (implicit GEMM over filter taps).
 // MODE 1: A rows are Winograd tiles and blockIdx.y is the position p = 4u + v; the loader fetches the four patch
@@ -55,22 +72,31 @@ struct ConvGeom {
 //        over the row's BN/4 lanes in ascending order, one atomicAdd per (row, q, cout tile) into a zeroed planar
 //        accumulator.  With at most two cout tiles the result does not depend on the order of the atomics
 //        (0 + a + b == 0 + b + a).  The activation itself need not be written (out == NULL).
-template <int NT, int MODE, bool RESPF = false, int BK = 32, bool PROJ = false>
+// GLDS:  the K-slabs go from global memory straight into LDS (no staging registers, no ds_write, no masking: invalid
+//        rows read a zero page).  The LDS image of a slab is lane-linear, i.e. unpadded rows; bank conflicts of the
+//        16-byte fragment reads are avoided by XOR-swizzling the 16-byte chunk index with the row ON THE SOURCE SIDE
+//        (lane of physical chunk p fetches logical chunk p ^ f(row); a reader of logical chunk c looks at c ^ f(row)).
+//        Ring of 3 slabs for BK = 16 (loads run two slabs ahead, `s_waitcnt vmcnt(loads of one slab)` before the
+//        barrier), 2 for BK = 32.  Measured motivation: without the register -> LDS stage the same loop runs at 96 %
+//        of the matrix peak instead of 83 %.
+template <int NT, int MODE, bool RESPF = false, int BK = 32, bool PROJ = false, bool GLDS = false>
 __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32_kernel(ConvGeom g)
 {
     constexpr int BN = 64 * NT;
-    constexpr int CG_LD = BK + 4;                  // padded LDS row (floats): 16-byte fragment reads conflict-free
+    constexpr int CG_LD = GLDS ? BK : BK + 4;      // LDS row (floats): padded (register staging) or swizzled (GLDS)
+    constexpr int NBUF = GLDS ? (BK == 16 ? 3 : 2) : 2;
     constexpr int TPR = BK / 4;                    // threads staging one row (one float4 each)
     constexpr int RPP = CG_THREADS / TPR;          // rows staged per pass
     constexpr int AR = CG_BM / RPP;                // A rows staged per thread
     constexpr int BROWS = BN / RPP;                // B rows staged per thread
     constexpr int NF4 = BK / 8;                    // float4 fragments per lane, tile and slab
     constexpr int CLD = BN + 4;                    // padded row of the epilogue staging tile (floats)
-    constexpr int A_ELEMS = 2 * CG_BM * CG_LD, B_ELEMS = 2 * BN * CG_LD;
+    constexpr int A_ELEMS = NBUF * CG_BM * CG_LD, B_ELEMS = NBUF * BN * CG_LD;
     constexpr int EPI_ROWS = (A_ELEMS + B_ELEMS >= CG_BM * CLD) ? CG_BM : 64;   // epilogue staged in 1 or 2 rounds
     constexpr int C_ELEMS = EPI_ROWS * CLD;
     constexpr int SMEM = (A_ELEMS + B_ELEMS) > C_ELEMS ? (A_ELEMS + B_ELEMS) : C_ELEMS;
     static_assert(MODE == 0 || BK == 32, "the fused Winograd loader is written for BK = 32");
+    static_assert(!GLDS || (MODE == 0 && !RESPF), "LDS-direct staging: plain convolution / GEMM without residual prefetch");
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float *As = smem, *Bs = smem + A_ELEMS;
     g.x += (int64_t)blockIdx.y * g.x_bs;
@@ -247,54 +273,137 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
         }
     }
 
-    // Pipeline: slab s is consumed from LDS buffer s & 1 while slab s+1 (already in registers, loaded one
-    // iteration earlier) is written to the other buffer between the MFMAs, and the global loads of slab s+2 are
-    // issued right behind it: a load has a whole iteration (64 MFMAs per wave) to land, and the LDS writes, address
-    // arithmetic and load issue all overlap the matrix pipe.
-    CG_LOAD_NEXT();
-    store_slab(0);
-    if (S > 1) CG_LOAD_NEXT();
-    __syncthreads();
-    for (int s = 0; s < S; ++s) {
-        const int buf = s & 1;
-        const float *Ab = &As[buf * CG_BM * CG_LD + (wm * 64 + r) * CG_LD + hh * (BK / 2)];
-        const float *Bb = &Bs[buf * BN * CG_LD + (wn * 32 * NT + r) * CG_LD + hh * (BK / 2)];
+    if constexpr (GLDS) {
+        // ---- LDS-direct pipeline -------------------------------------------------------------------------------
+        constexpr int RPW = 64 / TPR;                                   // rows one wave-load covers
+        constexpr int NL = AR + BROWS;                                  // loads per thread and slab
+        const int swz_ld = (BK == 16) ? ((lrow >> 2) & 3) : ((lrow >> 1) & 7);
+        const int csw = (((tid % TPR) ^ swz_ld) * 4);                   // logical chunk this lane fetches (floats)
+        const float *ga[AR], *gb[BROWS];
+        bool ga_ok[AR];
+        auto set_tap_g = [&](int tap) {
+            const int ky = tap / g.KW, kx = tap - ky * g.KW;
 #pragma unroll
-        for (int half = 0; half < NF4 / 2; ++half) {
-            float4 fa[2][2], fb[NT][2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    fa[i][q] = *reinterpret_cast<const float4 *>(Ab + i * 32 * CG_LD + half * 8 + q * 4);
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    fb[j][q] = *reinterpret_cast<const float4 *>(Bb + j * 32 * CG_LD + half * 8 + q * 4);
+            for (int i = 0; i < AR; ++i) {
+                const int iy = a_iy[i] + ky * g.dil, ix = a_ix[i] + kx * g.dil;
+                ga_ok[i] = a_ok[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                ga[i] = ga_ok[i] ? g.x + (((int64_t)a_n[i] * g.H + iy) * g.W + ix) * g.Cin + csw : cg_zero_page + csw;
             }
+        };
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+        for (int i = 0; i < BROWS; ++i) {
+            const int cob = n0 + lrow + RPP * i;
+            gb[i] = (cob < g.Cout) ? g.w + (int64_t)cob * taps * g.Cin + csw : cg_zero_page + csw;
+        }
+        set_tap_g(0);
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)smem;
+        const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(RPW * wave * BK * 4));
+        const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((A_ELEMS + RPW * wave * BK) * 4));
+        int gl_tap = 0, gl_c0 = 0;
+        auto issue_slab = [&](int ring) {
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+                cg_glds16(ga[i] + (ga_ok[i] ? gl_c0 : 0), a_dst + (unsigned)((ring * CG_BM + RPP * i) * BK * 4));
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) {
+                const bool ok = n0 + lrow + RPP * i < g.Cout;
+                cg_glds16(gb[i] + (ok ? (int64_t)gl_tap * g.Cin + gl_c0 : 0), b_dst + (unsigned)((ring * BN + RPP * i) * BK * 4));
+            }
+            gl_c0 += BK;
+            if (gl_c0 == g.Cin) {               // block-uniform
+                gl_c0 = 0;
+                ++gl_tap;
+                if (gl_tap < taps) set_tap_g(gl_tap);
+            }
+        };
+        const int swz_rd = (BK == 16) ? ((r >> 2) & 3) : ((r >> 1) & 7);
+        issue_slab(0);
+        if (NBUF == 3 && S > 1) issue_slab(1);
+        if (NBUF == 3 && S > 1) cg_wait_vm<NL>(); else cg_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < S; ++s) {
+            const int ring = s % NBUF;
+            if (s + NBUF - 1 < S) issue_slab((s + NBUF - 1) % NBUF);   // its buffer was read in iteration s - 1
+            const float *Ar = &As[ring * CG_BM * CG_LD + (wm * 64 + r) * CG_LD];
+            const float *Br = &Bs[ring * BN * CG_LD + (wn * 32 * NT + r) * CG_LD];
+#pragma unroll
+            for (int f = 0; f < NF4; ++f) {
+                const int pc = (((hh * NF4 + f) ^ swz_rd) * 4);         // physical position of logical chunk hh*NF4 + f
+                float4 fa[2], fb[NT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float4 *>(Ar + i * 32 * CG_LD + pc);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4 *>(Br + j * 32 * CG_LD + pc);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float av[2], bv[NT];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        av[i] = e == 0 ? fa[i][q].x : e == 1 ? fa[i][q].y : e == 2 ? fa[i][q].z : fa[i][q].w;
+                    for (int i = 0; i < 2; ++i) av[i] = e == 0 ? fa[i].x : e == 1 ? fa[i].y : e == 2 ? fa[i].z : fa[i].w;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        bv[j] = e == 0 ? fb[j][q].x : e == 1 ? fb[j][q].y : e == 2 ? fb[j][q].z : fb[j][q].w;
+                    for (int j = 0; j < NT; ++j) bv[j] = e == 0 ? fb[j].x : e == 1 ? fb[j].y : e == 2 ? fb[j].z : fb[j].w;
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
                 }
-                if (half == 0 && q == 0) {
-                    if (s + 1 < S) store_slab(buf ^ 1);     // slab s+1: registers -> the buffer read in iteration s-1
-                    if (s + 2 < S) CG_LOAD_NEXT();          // slab s+2: global -> registers
+            }
+            // slab s+1 must have landed (it was requested one or two iterations ago); the loads issued in this
+            // iteration (slab s + NBUF - 1) may stay in flight when the ring has three slots
+            if (NBUF == 3 && s + 2 < S) cg_wait_vm<NL>(); else cg_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // Pipeline: slab s is consumed from LDS buffer s & 1 while slab s+1 (already in registers, loaded one
+        // iteration earlier) is written to the other buffer between the MFMAs, and the global loads of slab s+2 are
+        // issued right behind it: a load has a whole iteration (64 MFMAs per wave) to land, and the LDS writes, address
+        // arithmetic and load issue all overlap the matrix pipe.
+        CG_LOAD_NEXT();
+        store_slab(0);
+        if (S > 1) CG_LOAD_NEXT();
+        __syncthreads();
+        for (int s = 0; s < S; ++s) {
+            const int buf = s & 1;
+            const float *Ab = &As[buf * CG_BM * CG_LD + (wm * 64 + r) * CG_LD + hh * (BK / 2)];
+            const float *Bb = &Bs[buf * BN * CG_LD + (wn * 32 * NT + r) * CG_LD + hh * (BK / 2)];
+    #pragma unroll
+            for (int half = 0; half < NF4 / 2; ++half) {
+                float4 fa[2][2], fb[NT][2];
+    #pragma unroll
+                for (int q = 0; q < 2; ++q) {
+    #pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        fa[i][q] = *reinterpret_cast<const float4 *>(Ab + i * 32 * CG_LD + half * 8 + q * 4);
+    #pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        fb[j][q] = *reinterpret_cast<const float4 *>(Bb + j * 32 * CG_LD + half * 8 + q * 4);
+                }
+    #pragma unroll
+                for (int q = 0; q < 2; ++q) {
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float av[2], bv[NT];
+    #pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            av[i] = e == 0 ? fa[i][q].x : e == 1 ? fa[i][q].y : e == 2 ? fa[i][q].z : fa[i][q].w;
+    #pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            bv[j] = e == 0 ? fb[j][q].x : e == 1 ? fb[j][q].y : e == 2 ? fb[j][q].z : fb[j][q].w;
+    #pragma unroll
+                        for (int i = 0; i < 2; ++i)
+    #pragma unroll
+                            for (int j = 0; j < NT; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    }
+                    if (half == 0 && q == 0) {
+                        if (s + 1 < S) store_slab(buf ^ 1);     // slab s+1: registers -> the buffer read in iteration s-1
+                        if (s + 2 < S) CG_LOAD_NEXT();          // slab s+2: global -> registers
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
+
     }
 
     // epilogue, staged through LDS so that global traffic is 16 bytes per lane and row-contiguous:
@@ -408,7 +517,7 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
 // matrix work of two others) unless the launch has at most two blocks per CU anyway, or the residual-prefetch
 // variant is used (it needs the registers).
 struct CgPlan {
-    bool narrow, respf;
+    bool narrow, respf, glds;
     int slab, tiles_m, tiles_n;
 };
 
@@ -425,6 +534,8 @@ static CgPlan cg_plan(int64_t M, int Cout, int batch, bool has_res, bool res_vec
     if (force && force[0] == '1') p.slab = 16;
     if (force && force[0] == '3') p.slab = 32;
     if (p.respf) p.slab = 32;
+    static const char *noglds = getenv("EMP_CONV_NO_GLDS");          // experiments only
+    p.glds = !p.respf && !noglds;
     return p;
 }
 
@@ -466,13 +577,15 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     g.tiles_n = pl.tiles_n;
     const int T = g.tiles_m * g.tiles_n;
     const int grid = 8 * ((T + 7) / 8);
-#define CG_GO(NT_, RES_, BK_) hipLaunchKernelGGL((conv_igemm_f32_kernel<NT_, 0, RES_, BK_>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g)
+#define CG_GO(NT_, RES_, BK_, GL_) hipLaunchKernelGGL((conv_igemm_f32_kernel<NT_, 0, RES_, BK_, false, GL_>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g)
     if (narrow) {
-        if (respf) CG_GO(1, true, 32);
-        else { if (bk16) CG_GO(1, false, 16); else CG_GO(1, false, 32); }
+        if (respf) CG_GO(1, true, 32, false);
+        else if (pl.glds) { if (bk16) CG_GO(1, false, 16, true); else CG_GO(1, false, 32, true); }
+        else { if (bk16) CG_GO(1, false, 16, false); else CG_GO(1, false, 32, false); }
     } else {
-        if (respf) CG_GO(2, true, 32);
-        else { if (bk16) CG_GO(2, false, 16); else CG_GO(2, false, 32); }
+        if (respf) CG_GO(2, true, 32, false);
+        else if (pl.glds) { if (bk16) CG_GO(2, false, 16, true); else CG_GO(2, false, 32, true); }
+        else { if (bk16) CG_GO(2, false, 16, false); else CG_GO(2, false, 32, false); }
     }
 #undef CG_GO
     EMP_CHECK_LAUNCH("emp_conv_bn_act_nhwc");
@@ -509,8 +622,10 @@ extern "C" int emp_conv_bn_act_proj_nhwc(const float *x, const float *w_okkc, co
     g.tiles_n = pl.tiles_n;
     const int T = g.tiles_m * g.tiles_n;
     const int grid = 8 * ((T + 7) / 8);
-    if (pl.slab == 16) hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, false, 16, true>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
-    else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, false, 32, true>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g);
+#define CG_GOP(BK_, GL_) hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, false, BK_, true, GL_>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g)
+    if (pl.glds) { if (pl.slab == 16) CG_GOP(16, true); else CG_GOP(32, true); }
+    else { if (pl.slab == 16) CG_GOP(16, false); else CG_GOP(32, false); }
+#undef CG_GOP
     EMP_CHECK_LAUNCH("emp_conv_bn_act_proj_nhwc");
     return EMP_OK;
 }
@@ -646,13 +761,15 @@ extern "C" int emp_gemm_nt_batched(const float *A, const float *B, int batch, in
     g.tiles_n = pl.tiles_n;
     const int T = g.tiles_m * g.tiles_n;
     dim3 grid(8 * ((T + 7) / 8), batch);
+#define CG_GOG(NT_, BK_, GL_) hipLaunchKernelGGL((conv_igemm_f32_kernel<NT_, 0, false, BK_, false, GL_>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g)
     if (narrow) {
-        if (bk16) hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0, false, 16>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
-        else hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0, false, 32>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+        if (pl.glds) { if (bk16) CG_GOG(1, 16, true); else CG_GOG(1, 32, true); }
+        else { if (bk16) CG_GOG(1, 16, false); else CG_GOG(1, 32, false); }
     } else {
-        if (bk16) hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, false, 16>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
-        else hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, false, 32>), grid, dim3(CG_THREADS), 0, emp_stream(stream), g);
+        if (pl.glds) { if (bk16) CG_GOG(2, 16, true); else CG_GOG(2, 32, true); }
+        else { if (bk16) CG_GOG(2, 16, false); else CG_GOG(2, 32, false); }
     }
+#undef CG_GOG
     EMP_CHECK_LAUNCH("emp_gemm_nt_batched");
     return EMP_OK;
 }
