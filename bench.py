@@ -55,7 +55,7 @@ PMC_TRAFFIC_BYTES_PER_VOXEL = {
 PMC_TRAFFIC_RATIO = {
     # HBM traffic (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes, averaged over the launches of a timed pass with
     # the tuned implementation choices replayed (--load-tune): profiles/r1_pmc_bench_dense.md
-    'emp_conv_bn_act_nhwc': 1.13, 'emp_bn_act_nhwc': 1.0, 'emp_dwconv_nhwc': 1.12, 'emp_upsample_bilinear': 1.0,
+    'emp_conv_bn_act_nhwc': 1.16, 'emp_bn_act_nhwc': 1.0, 'emp_dwconv_nhwc': 1.12, 'emp_upsample_bilinear': 1.0,
 }
 DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 'emp_conv_bn_act_nhwc',
                  'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
