@@ -205,10 +205,17 @@ def merge_objects_from_trackers(object_trackers, pixel_vote_thr=2, cluster_iou_t
     for comp in nx.connected_components(graph):
         if len(comp) < min_cluster_size:
             continue
-        cluster_graph = merge_clusters(create_graph_of_clusters(graph.subgraph(comp), cluster_iou_thr))
+        if all(iou > cluster_iou_thr for _, _, iou in graph.edges(comp, data='iou')):
+            # every edge survives the IoU cut, so the component stays one cluster (create_graph_of_clusters yields a
+            # single node, merge_clusters has nothing to do): skip the two graph copies.  The member order does
+            # not matter downstream (box merging is commutative, the vote counts coverage).
+            cluster_sets = [set(comp)]
+        else:
+            cluster_graph = merge_clusters(create_graph_of_clusters(graph.subgraph(comp), cluster_iou_thr))
+            cluster_sets = [cluster_graph.nodes[node]['cluster'] for node in cluster_graph.nodes]
         clusters = []
-        for node in cluster_graph.nodes:
-            cluster = list(cluster_graph.nodes[node]['cluster'])
+        for cset in cluster_sets:
+            cluster = list(cset)
             if len(cluster) < min_cluster_size:
                 continue
             merged_box = graph.nodes[cluster[0]]['box']
