@@ -1,17 +1,20 @@
 // D4: implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) with the BatchNorm / residual /
 // ReLU epilogue fused into the accumulator write-back.  gfx950 only.
 //
-//   GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin.  NHWC activations make every K-slab (32 input
-//   channels of one filter tap) of an A row 128 contiguous bytes; weights are stored (Cout, KH, KW, Cin) so a B
-//   row's slab is contiguous as well.
-//   Block = 256 threads = 2x2 waves, block tile 128 (pixels) x 128 (couts) x 32 (K); each wave owns 64x64 =
-//   2x2 MFMA tiles of 32x32 (4 accumulators x 16 VGPRs).  Global -> registers -> LDS staging, two LDS buffers,
-//   one barrier per slab: the loads of slab s+1 are in flight while slab s runs its 64 MFMAs.
-//   LDS rows are padded to 36 floats: the 16-byte fragment reads of 16 consecutive lanes then cover all 64 banks
-//   exactly once.
-//   K order inside a slab: the MFMA k-step j (0..15) consumes channels j (lanes 0-31) and 16 + j (lanes 32-63),
-//   so a lane's 16 operands per slab are 64 contiguous bytes in LDS (four ds_read_b128) -- see emp_hip.h for the
-//   resulting summation order, which the oracle reproduces bit for bit.
+//   GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin.  NHWC activations make every K-slab (16 or 32
+//   input channels of one filter tap) of an A row contiguous; weights are stored (Cout, KH, KW, Cin) so a B row's
+//   slab is contiguous as well.
+//   Block = 256 threads = 2x2 waves, block tile 128 (pixels) x 128 (couts; 64 for narrow layers); each wave owns
+//   64x64 = 2x2 MFMA tiles of 32x32 (4 accumulators x 16 VGPRs).  One barrier per K-slab.
+//   Staging, two variants (template flag GLDS):
+//     LDS-direct (default): global_load_lds_dwordx4, unpadded lane-linear LDS rows with a source-side XOR swizzle,
+//       ring of 3 slabs (BK = 16, three blocks per CU) or 2 (BK = 32), counted vmcnt before a raw barrier;
+//     global -> registers -> LDS (residual-prefetch variant, fused Winograd loader): LDS rows padded by 4 floats so
+//       that the 16-byte fragment reads of 16 consecutive lanes cover all 64 banks exactly once; the loads of slab
+//       s+2 are issued and slab s+1 is written to LDS between the MFMAs of slab s.
+//   K order inside a slab of BK channels: the MFMA k-step j consumes channels j (lanes 0-31) and BK/2 + j (lanes
+//   32-63), so a lane's operands are contiguous in LDS (ds_read_b128) -- see emp_hip.h for the resulting summation
+//   order, which the oracle reproduces bit for bit.
 //   blockIdx -> tile: consecutive hardware block ids go to different XCDs; tiles are renumbered so that each XCD
 //   (its own L2) works on a contiguous range of tiles, cout-tiles fastest, and the A slabs shared by the cout
 //   tiles of one pixel tile are fetched once per XCD.
