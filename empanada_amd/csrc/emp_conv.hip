@@ -9,7 +9,7 @@
 //   Staging, two variants (template flag GLDS):
 //     LDS-direct (default): global_load_lds_dwordx4, unpadded lane-linear LDS rows with a source-side XOR swizzle,
 //       ring of 3 slabs (BK = 16, three blocks per CU) or 2 (BK = 32), counted vmcnt before a raw barrier;
-//     global -> registers -> LDS (residual-prefetch variant, fused Winograd loader): LDS rows padded by 4 floats so
+//     global -> registers -> LDS (fused Winograd loader, EMP_CONV_NO_GLDS): LDS rows padded by 4 floats so
 //       that the 16-byte fragment reads of 16 consecutive lanes cover all 64 banks exactly once; the loads of slab
 //       s+2 are issued and slab s+1 is written to LDS between the MFMAs of slab s.
 //   K order inside a slab of BK channels: the MFMA k-step j consumes channels j (lanes 0-31) and BK/2 + j (lanes
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
     constexpr int C_ELEMS = EPI_ROWS * CLD;
     constexpr int SMEM = (A_ELEMS + B_ELEMS) > C_ELEMS ? (A_ELEMS + B_ELEMS) : C_ELEMS;
     static_assert(MODE == 0 || BK == 32, "the fused Winograd loader is written for BK = 32");
-    static_assert(!GLDS || (MODE == 0 && !RESPF), "LDS-direct staging: plain convolution / GEMM without residual prefetch");
+    static_assert(!GLDS || MODE == 0, "LDS-direct staging: plain convolution / GEMM loader only");
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float *As = smem, *Bs = smem + A_ELEMS;
     g.x += (int64_t)blockIdx.y * g.x_bs;
@@ -538,7 +538,7 @@ static CgPlan cg_plan(int64_t M, int Cout, int batch, bool has_res, bool res_vec
     if (force && force[0] == '3') p.slab = 32;
     if (p.respf) p.slab = 32;
     static const char *noglds = getenv("EMP_CONV_NO_GLDS");          // experiments only
-    p.glds = !p.respf && !noglds;
+    p.glds = !noglds;
     return p;
 }
 
@@ -582,11 +582,11 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     const int grid = 8 * ((T + 7) / 8);
 #define CG_GO(NT_, RES_, BK_, GL_) hipLaunchKernelGGL((conv_igemm_f32_kernel<NT_, 0, RES_, BK_, false, GL_>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g)
     if (narrow) {
-        if (respf) CG_GO(1, true, 32, false);
+        if (respf) { if (pl.glds) CG_GO(1, true, 32, true); else CG_GO(1, true, 32, false); }
         else if (pl.glds) { if (bk16) CG_GO(1, false, 16, true); else CG_GO(1, false, 32, true); }
         else { if (bk16) CG_GO(1, false, 16, false); else CG_GO(1, false, 32, false); }
     } else {
-        if (respf) CG_GO(2, true, 32, false);
+        if (respf) { if (pl.glds) CG_GO(2, true, 32, true); else CG_GO(2, true, 32, false); }
         else if (pl.glds) { if (bk16) CG_GO(2, false, 16, true); else CG_GO(2, false, 32, true); }
         else { if (bk16) CG_GO(2, false, 16, false); else CG_GO(2, false, 32, false); }
     }
