@@ -144,6 +144,29 @@ def test_group_pixels_vs_oracle(hip, K, step):
     np.testing.assert_array_equal(_group(hip, ctr, off, step), OP.group_pixels(ctr, off, step=step))
 
 
+@pytest.mark.parametrize('K,step,noise', [(9, 1, 0.0), (20, 1, 0.3), (21, 1, 0.0), (150, 1, 0.5), (900, 1, 0.2),
+                                           (40, 4, 0.0), (300, 4, 1.0)])
+def test_group_pixels_structured_offsets(hip, K, step, noise):
+    """offsets that point at nearby centres (what a trained head emits): the per-block candidate pruning is active.
+    Integer offsets give exact ties between equidistant centres (first index must win), a band of huge offsets lands
+    farther than 1e5 from every centre (id 0 when K > 20), one row holds NaN / inf offsets (full walk)."""
+    from oracle import postprocess as OP
+    rng = np.random.default_rng(K * 13 + step)
+    h, w = 128, 192
+    ctr = np.stack([rng.integers(0, h, K), rng.integers(0, w, K)], axis=1).astype(np.int64)
+    ctr[K // 2] = ctr[0]                                         # a duplicated centre: the lower index wins
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing='ij')
+    d2 = (yy[..., None] - ctr[:, 0]) ** 2 + (xx[..., None] - ctr[:, 1]) ** 2
+    near = ctr[np.argmin(d2, axis=-1)]
+    off = np.stack([near[..., 0] - yy, near[..., 1] - xx]).astype(np.float32)[None] * step
+    off[0, :, :, : w // 2] *= 0.5                                # half way: equidistant pairs of centres appear
+    off += rng.normal(0, noise, off.shape).astype(np.float32)
+    off[0, :, 40:44] += 3e5                                      # beyond the 1e5 ceiling
+    off[0, 0, 50, :20] = np.nan
+    off[0, 1, 50, 20:40] = np.inf
+    np.testing.assert_array_equal(_group(hip, ctr, off, step), OP.group_pixels(ctr, off, step=step))
+
+
 def test_fuse_golden_and_random(hip):
     from oracle import postprocess as OP
     g = load_golden('merge_sem_ins')

@@ -310,6 +310,40 @@ def test_model_forward_with_hip_convolutions(force):
         assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (force, k, err, scale)
 
 
+@pytest.mark.parametrize('encoder,force', [('resnet50', 'direct'), ('resnet50', 'tuned'), ('regnety_6p4gf', 'direct')])
+def test_bifpn_forward_with_hip_convolutions(encoder, force):
+    """D1, second model family (models/panoptic_bifpn.py:98-108): PanopticBiFPN through the same graph rewrite
+    (fused conv + BN, depthwise, up-sampling kernels) against the host module, same tolerance as PanopticDeepLab."""
+    import copy
+    from empanada_amd.models import PanopticBiFPN, prepare_for_inference, synthesize_weights, tune_fused_convs
+    from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
+    torch.manual_seed(0)
+    m = synthesize_weights(PanopticBiFPN(encoder=encoder, num_classes=1)).eval()
+    x = torch.randn(2, 1, 128, 128)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = m(x)
+        g = prepare_for_inference(copy.deepcopy(m), 'cuda')
+        sites = [mod for mod in g.modules() if isinstance(mod, FusedConvBNAct)]
+        assert len(sites) > 20
+        if force == 'tuned':
+            rep = tune_fused_convs(g, xd, reps=2)
+            assert len(rep) > 20
+        else:
+            g(xd)
+            n = 0
+            for mod in sites:
+                if mod._seen is not None and force in mod.candidates(mod._seen[1]):
+                    mod.impl = force
+                    n += 1
+            assert n > 20
+        out = g(xd)
+    for k in ref:
+        scale = float(ref[k].abs().max())
+        err = float((out[k].float().cpu() - ref[k]).abs().max())
+        assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (encoder, force, k, err, scale)
+
+
 def test_sharded_path_world1_equals_tracker_path():
     """bench.py's path (sharded.py with one rank: tables -> chain -> filters on tables -> fill from the run
     table) paints exactly the volume of track_stack -> filters -> fill_volume_device."""
