@@ -76,6 +76,8 @@ def parse():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--batch', type=int, default=32, help='slices per model call')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
+    ap.add_argument('--model', default='pdl_r50', choices=sorted(MODELS),
+                    help='pdl_r50 is the configuration the metric is quoted on; the others are side measurements')
     ap.add_argument('--save-tune', default=None, help='write the tuned conv implementation per call site (json)')
     ap.add_argument('--load-tune', default=None, help='replay conv implementations from a --save-tune file')
     ap.add_argument('--conv-impls', default=None,
@@ -105,11 +107,25 @@ def build_inputs(D, S, device, seed_offset=0):
     return vol, heads, int(cls.shape[0] - 1)
 
 
+# --model name -> label in config.workload (the FLOP count below is only known for the headline model)
+MODELS = {'pdl_r50': 'PanopticDeepLab/ResNet-50', 'bifpn_r50': 'PanopticBiFPN/ResNet-50',
+          'bifpn_regnety': 'PanopticBiFPN/RegNetY-6.4GF'}
+
+
+def build_model(name):
+    from empanada_amd.models import PanopticBiFPN, PanopticDeepLab, synthesize_weights
+    if name == 'pdl_r50':
+        model = PanopticDeepLab(encoder='resnet50', num_classes=1)
+    else:
+        model = PanopticBiFPN(encoder={'bifpn_r50': 'resnet50', 'bifpn_regnety': 'regnety_6p4gf'}[name], num_classes=1)
+    return synthesize_weights(model)
+
+
 class Pipeline:
     def __init__(self, args, device):
-        from empanada_amd.models import PanopticDeepLab, prepare_for_inference, synthesize_weights
+        from empanada_amd.models import prepare_for_inference
         self.dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[args.dtype]
-        model = synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1))
+        model = build_model(args.model)
         with torch.no_grad():                     # O(1) logits like a trained model (synthetic He weights are hot)
             for head in (model.semantic_head, model.ins_center, model.ins_xy):
                 head.head[1].weight.mul_(1e-3)
@@ -321,7 +337,7 @@ def main_orthoplane(args, device, rank, world):
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f32' if args.dtype == 'fp32' else args.dtype, 'data': 'synthetic',
         'config': {'workload': f'orthoplane (xy/xz/yz) inference + instance consensus, {S}^3 uint8 volume, '
-                               f'PanopticDeepLab/ResNet-50 C=1 forward on every slice of every plane + HIP '
+                               f'{MODELS[args.model]} C=1 forward on every slice of every plane + HIP '
                                f'post-processing on planted heads, {n_obj} planted objects, slices sharded over '
                                f'{world} rank(s)',
                    'mode': 'orthoplane', 'objects_found': int(n_found)},
@@ -333,14 +349,13 @@ def main_orthoplane(args, device, rank, world):
 def cpu_baseline(args, vol_u8, heads, n_slices):
     """The oracle chain (CPU restatement of the reference) + torch-CPU forward on a bounded sample of the
     same workload: the first n_slices slices.  kind = 'port'."""
-    from empanada_amd.models import PanopticDeepLab, synthesize_weights
     from oracle import postprocess as OP
     from oracle import rle_ops as OR
     from oracle import rle_seg as OS
     n = min(n_slices, vol_u8.shape[0])
     cores = min(16, os.cpu_count() or 1)          # the GPU box grants a 16-core share per GPU
     torch.set_num_threads(cores)
-    model = synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)).eval()
+    model = build_model(args.model).eval()
     x = vol_u8[:n].cpu().float().unsqueeze(1)
     x = (x - 255 * NORM['mean']) / (255 * NORM['std'])
     sem, ctr, off = (heads[k][:n].cpu().numpy() for k in ('sem', 'ctr_hmp', 'offsets'))
@@ -552,13 +567,13 @@ def main():
             'value': round(vox_total / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_step, 2), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'stack (xy) inference, {D * world}x{S}x{S} uint8 volume, PanopticDeepLab/ResNet-50 '
+            'config': {'workload': f'stack (xy) inference, {D * world}x{S}x{S} uint8 volume, {MODELS[args.model]} '
                                    f'C=1 fp-forward on every slice + HIP post-processing on planted heads '
                                    f'(ks=7, full-res heads), {n_obj} planted objects per rank',
                        'mode': 'stack', 'slices_per_rank': D, 'batch': args.batch,
                        'objects_found': int(len(np.unique(host_out.numpy())) - 1)},
             'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'forward_end_to_slab_on_host': round(float(post_ms), 2),
-                             'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2),
+                             'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2) if args.model == 'pdl_r50' else None,
                              'pipelined': not args.no_pipeline, 'conv_impls': pipe.tuned,
                              'host_chain_s': round(float(np.mean(pipe.timers.get('chain_s', [0]))), 4)},
             'hip_calls_ms': per_call,
