@@ -31,13 +31,14 @@ sys.path.insert(0, ROOT)
 
 ENGINE = dict(thing_list=[1], label_divisor=20000, stuff_area=64, void_label=0, nms_threshold=0.1, nms_kernel=7,
               confidence_thr=0.3, median_kernel_size=7)      # projects/mitonet/configs/mmm_median_inference.yaml
+LABELS = [1]                                                  # --things T: classes 1..T, all of them things
 MATCH = dict(merge_iou_thr=0.25, merge_ioa_thr=0.25)
 FILTERS = dict(min_size=500, min_span=4)
 NORM = dict(mean=0.508979, std=0.148561)                      # MitoNet norms
 # Algorithmic HBM bytes per voxel of the single-kernel ABI calls, C = 1, full-res heads.
 # f = fraction of voxels whose class is a thing (measured on the run's own data): only those read offsets.
 ALG_BYTES = {
-    'emp_median_harden_stack': lambda f: 4 + 1,        # read prob fp32, write sem u8
+    'emp_median_harden_stack': lambda f: 4 * (1 if len(LABELS) == 1 else len(LABELS) + 1) + 1,  # prob fp32 x C, sem u8
     'emp_find_centers': lambda f: 4,                   # read heatmap
     'emp_group_pixels': lambda f: 1 + 8 * f + 2,       # read sem u8, offsets of voted pixels, write ids u16
     'emp_fuse_apply': lambda f: 1 + 2 + 4,             # read sem u8 + ids u16, write pan u32
@@ -78,6 +79,8 @@ def parse():
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--model', default='pdl_r50', choices=sorted(MODELS),
                     help='pdl_r50 is the configuration the metric is quoted on; the others are side measurements')
+    ap.add_argument('--things', type=int, default=1,
+                    help='thing classes (1 = binary MitoNet, the headline; T > 1 = softmax over background + T classes)')
     ap.add_argument('--save-tune', default=None, help='write the tuned conv implementation per call site (json)')
     ap.add_argument('--load-tune', default=None, help='replay conv implementations from a --save-tune file')
     ap.add_argument('--conv-impls', default=None,
@@ -92,15 +95,16 @@ def parse():
     return ap.parse_args()
 
 
-def build_inputs(D, S, device, seed_offset=0):
+def build_inputs(D, S, device, seed_offset=0, things=1):
     from empanada_amd import synthetic as SY
     shape = (D, S, S)
     from empanada_amd.data import DeviceVolume
     vol = DeviceVolume(SY.em_volume(shape, seed=1234 + seed_offset), NORM['mean'], NORM['std'], 16, device)
-    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321 + seed_offset)
+    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321 + seed_offset, n_classes=things)
     heads = {'sem': [], 'ctr_hmp': [], 'offsets': []}
     for s in range(0, D, 64):                    # chunked to bound the generator's temporaries
-        h = SY.planted_heads(lab, cls, 'xy', device=device, slices=slice(s, min(D, s + 64)), seed=99 + s)
+        h = SY.planted_heads(lab, cls, 'xy', device=device, slices=slice(s, min(D, s + 64)), seed=99 + s,
+                             n_classes=things)
         for k in heads:
             heads[k].append(h[k])
     heads = {k: torch.cat(v, dim=0).contiguous() for k, v in heads.items()}
@@ -114,10 +118,11 @@ MODELS = {'pdl_r50': 'PanopticDeepLab/ResNet-50', 'bifpn_r50': 'PanopticBiFPN/Re
 
 def build_model(name):
     from empanada_amd.models import PanopticBiFPN, PanopticDeepLab, synthesize_weights
+    nc = 1 if len(LABELS) == 1 else len(LABELS) + 1              # binary head, or background + T classes
     if name == 'pdl_r50':
-        model = PanopticDeepLab(encoder='resnet50', num_classes=1)
+        model = PanopticDeepLab(encoder='resnet50', num_classes=nc)
     else:
-        model = PanopticBiFPN(encoder={'bifpn_r50': 'resnet50', 'bifpn_regnety': 'regnety_6p4gf'}[name], num_classes=1)
+        model = PanopticBiFPN(encoder={'bifpn_r50': 'resnet50', 'bifpn_regnety': 'regnety_6p4gf'}[name], num_classes=nc)
     return synthesize_weights(model)
 
 
@@ -172,13 +177,15 @@ class Pipeline:
         heads"""
         hi = dv.n_slices(axis) if hi is None else hi
         h, w = dv.plane_shape(axis)
-        prob = torch.empty((hi - lo, 1, h, w), dtype=torch.float32, device=self.device)
+        nc = 1 if len(LABELS) == 1 else len(LABELS) + 1
+        prob = torch.empty((hi - lo, nc, h, w), dtype=torch.float32, device=self.device)
         chk = torch.zeros((), dtype=torch.float64, device=self.device)
         for s, x in dv.batches(axis, self.batch, lo, hi):
             if self.dtype != torch.float32:
                 x = x.to(self.dtype)
             out = self.model(x.contiguous(memory_format=torch.channels_last))
-            prob[s - lo:s - lo + x.shape[0]] = torch.sigmoid(out['sem_logits'][..., :h, :w].float())
+            logits = out['sem_logits'][..., :h, :w].float()          # logits_to_prob, engines.py:22-30
+            prob[s - lo:s - lo + x.shape[0]] = torch.sigmoid(logits) if nc == 1 else torch.softmax(logits, dim=1)
             chk += out['ctr_hmp'].float().sum(dtype=torch.float64) + out['offsets'].float().sum(dtype=torch.float64)
         return prob, chk + prob.sum(dtype=torch.float64)
 
@@ -191,7 +198,7 @@ class Pipeline:
                                              coarse_boundaries=False, **ENGINE)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        vol = sharded.sharded_stack_volume(pan, [1], ENGINE['thing_list'], ENGINE['label_divisor'],
+        vol = sharded.sharded_stack_volume(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'],
                                            min_size=FILTERS['min_size'], min_span=FILTERS['min_span'], **MATCH)
         out_host.copy_(vol.view(torch.int32), non_blocking=True)
         t2 = time.perf_counter()
@@ -363,16 +370,16 @@ def cpu_baseline(args, vol_u8, heads, n_slices):
     with torch.no_grad():
         for i in range(n):
             out = model(x[i:i + 1])
-            _ = torch.sigmoid(out['sem_logits'])
+            _ = torch.sigmoid(out['sem_logits']) if len(LABELS) == 1 else torch.softmax(out['sem_logits'], dim=1)
     t_conv = time.perf_counter() - t0
     pans = OP.engine3d_stack([sem[t:t + 1] for t in range(n)], [ctr[t:t + 1] for t in range(n)],
                              [off[t:t + 1] for t in range(n)], coarse_boundaries=False, render=True, **ENGINE)
     pans = [p.squeeze() for p in pans]
     matchers = OS.create_matchers(ENGINE['thing_list'], ENGINE['label_divisor'], MATCH['merge_iou_thr'],
                                   MATCH['merge_ioa_thr'])
-    stack = OS.forward_matching(pans, matchers, [1], ENGINE['label_divisor'], ENGINE['thing_list'])
+    stack = OS.forward_matching(pans, matchers, LABELS, ENGINE['label_divisor'], ENGINE['thing_list'])
     shape = (len(pans),) + pans[0].shape
-    trs = OS.create_axis_trackers(['xy'], [1], ENGINE['label_divisor'], shape)['xy']
+    trs = OS.create_axis_trackers(['xy'], LABELS, ENGINE['label_divisor'], shape)['xy']
     for idx, rs in OS.backward_matching(stack, matchers, len(pans)):
         OS.update_trackers(rs, idx, trs)
     OS.finish_tracking(trs)
@@ -389,7 +396,7 @@ def cpu_baseline(args, vol_u8, heads, n_slices):
     from empanada_amd.inference import sharded
     sub = {k: heads[k][:n].contiguous() for k in heads}
     pan = sharded.sharded_panoptic_stack(sub['sem'], sub['ctr_hmp'], sub['offsets'], coarse_boundaries=False, **ENGINE)
-    got = sharded.sharded_stack_volume(pan, [1], ENGINE['thing_list'], ENGINE['label_divisor'],
+    got = sharded.sharded_stack_volume(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'],
                                        min_size=FILTERS['min_size'], min_span=FILTERS['min_span'], **MATCH)
     got = got.view(torch.int32).cpu().numpy().astype(np.uint32)
     pq, n_gt, n_pred, n_match = volume_pq(out, got)
@@ -425,6 +432,10 @@ def main():
     _hip.load()
     torch.backends.cudnn.benchmark = True
 
+    if args.things > 1:
+        assert args.mode == 'stack', '--things > 1 is implemented for the stack mode'
+        LABELS[:] = list(range(1, args.things + 1))
+        ENGINE['thing_list'] = list(LABELS)
     if args.mode == 'orthoplane':
         main_orthoplane(args, device, rank, world)
         if world > 1:
@@ -432,7 +443,7 @@ def main():
         return
     D, S = args.depth, args.size
     log(f'building inputs {D}x{S}x{S}')
-    vol, heads, n_obj = build_inputs(D, S, device, seed_offset=rank)
+    vol, heads, n_obj = build_inputs(D, S, device, seed_offset=rank, things=args.things)
     log(f'inputs ready ({n_obj} planted objects); building model')
     pipe = Pipeline(args, device)
     if not args.no_tune:
@@ -480,9 +491,9 @@ def main():
                 post.wait_event(fwd_done[k])
                 pan = sharded.sharded_panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'],
                                                      coarse_boundaries=False, **ENGINE)
-                table, host = sharded.sharded_tables(pan, [1], ENGINE['thing_list'], ENGINE['label_divisor'])
+                table, host = sharded.sharded_tables(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'])
                 tc = time.perf_counter()
-                final = sharded.gather_tables_and_chain(host, pan.shape[0], [1], ENGINE['thing_list'],
+                final = sharded.gather_tables_and_chain(host, pan.shape[0], LABELS, ENGINE['thing_list'],
                                                         ENGINE['label_divisor'], min_size=FILTERS['min_size'],
                                                         min_span=FILTERS['min_span'], **MATCH)
                 pipe.timers.setdefault('chain_s', []).append(time.perf_counter() - tc)
@@ -516,7 +527,10 @@ def main():
         ms_step = dt / args.steps * 1e3
         fwd_ms = np.mean([ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(args.steps)])
         post_ms = np.mean([ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(args.steps)])
-        thing_frac = float((heads['sem'] >= ENGINE['confidence_thr']).float().mean().item())
+        if len(LABELS) == 1:
+            thing_frac = float((heads['sem'] >= ENGINE['confidence_thr']).float().mean().item())
+        else:
+            thing_frac = float((heads['sem'].argmax(dim=1) > 0).float().mean().item())
         vox = float(D) * S * S
         # per ABI call: launches, total ms and algorithmic bytes inside the timed region.  The per-voxel kernels
         # process the whole slab in one launch (ALG_BYTES x voxels); the dense-path kernels report their bytes
@@ -568,12 +582,12 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(ms_step, 2), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else args.dtype, 'data': 'synthetic',
             'config': {'workload': f'stack (xy) inference, {D * world}x{S}x{S} uint8 volume, {MODELS[args.model]} '
-                                   f'C=1 fp-forward on every slice + HIP post-processing on planted heads '
+                                   f'C={1 if len(LABELS) == 1 else len(LABELS) + 1} fp-forward on every slice + HIP post-processing on planted heads '
                                    f'(ks=7, full-res heads), {n_obj} planted objects per rank',
                        'mode': 'stack', 'slices_per_rank': D, 'batch': args.batch,
                        'objects_found': int(len(np.unique(host_out.numpy())) - 1)},
             'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'forward_end_to_slab_on_host': round(float(post_ms), 2),
-                             'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2) if args.model == 'pdl_r50' else None,
+                             'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2) if args.model == 'pdl_r50' and len(LABELS) == 1 else None,
                              'pipelined': not args.no_pipeline, 'conv_impls': pipe.tuned,
                              'host_chain_s': round(float(np.mean(pipe.timers.get('chain_s', [0]))), 4)},
             'hip_calls_ms': per_call,
