@@ -56,7 +56,7 @@ PMC_TRAFFIC_BYTES_PER_VOXEL = {
 PMC_TRAFFIC_RATIO = {
     # HBM traffic (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes, averaged over the launches of a timed pass with
     # the tuned implementation choices replayed (--load-tune): profiles/r1_pmc_bench_dense.md
-    'emp_conv_bn_act_nhwc': 1.16, 'emp_bn_act_nhwc': 1.0, 'emp_dwconv_nhwc': 1.12, 'emp_upsample_bilinear': 1.0,
+    'emp_conv_bn_act_nhwc': 1.18, 'emp_bn_act_nhwc': 1.0, 'emp_dwconv_nhwc': 1.06, 'emp_upsample_bilinear': 1.2,
 }
 DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 'emp_conv_bn_act_nhwc',
                  'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
@@ -75,10 +75,13 @@ def parse():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--depth', type=int, default=256, help='slices per rank')
     ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--batch', type=int, default=32, help='slices per model call')
+    ap.add_argument('--batch', type=int, default=128,
+                    help='slices of 512 x 512 per model call; larger slices get proportionally fewer per call '
+                         '(same pixels per call: the largest activations stay at 2 GiB)')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--model', default='pdl_r50', choices=sorted(MODELS),
                     help='pdl_r50 is the configuration the metric is quoted on; the others are side measurements')
+    ap.add_argument('--tune-batch', type=int, default=32, help='slices of 512 x 512 the conv tuner times each site on')
     ap.add_argument('--things', type=int, default=1,
                     help='thing classes (1 = binary MitoNet, the headline; T > 1 = softmax over background + T classes)')
     ap.add_argument('--save-tune', default=None, help='write the tuned conv implementation per call site (json)')
@@ -137,10 +140,14 @@ class Pipeline:
         self.model = prepare_for_inference(model, device, self.dtype)
         self.device = device
         self.batch = args.batch
+        self.tune_batch = args.tune_batch
         self.timers = {}
         self.tuned = {}
         self.conv_impls = args.conv_impls.split(',') if args.conv_impls else None
         self.post_stream = torch.cuda.Stream(device=device)
+
+    def slices_per_call(self, h, w):
+        return max(1, self.batch * 512 * 512 // max(h * w, 1))
 
     @torch.no_grad()
     def tune(self, size, save=None, load=None):
@@ -160,13 +167,16 @@ class Pipeline:
             self.tuned = counts
             log(f'conv call sites loaded from {load}: {counts}')
             return
-        x = torch.rand((self.batch, 1, size, size), device=self.device).contiguous(memory_format=torch.channels_last)
+        # tuned on a quarter of a call's slices: the ranking of the hand-written forms does not change with the batch,
+        # and MIOpen's exhaustive find on the full-size shapes of all 66 sites would take minutes of warm-up
+        n = max(1, min(self.slices_per_call(size, size), self.tune_batch * 512 * 512 // (size * size)))
+        x = torch.rand((n, 1, size, size), device=self.device).contiguous(memory_format=torch.channels_last)
         rep = tune_fused_convs(self.model, x, allow=self.conv_impls)
         for _, (best, _) in rep.items():
             counts[best] = counts.get(best, 0) + 1
         self.tuned = counts
         saved = sum(t['miopen'] - min(t.values()) for _, t in rep.values())
-        log(f'conv call sites tuned: {counts}; isolated saving {saved:.2f} ms per batch of {self.batch}')
+        log(f'conv call sites tuned: {counts}; isolated saving {saved:.2f} ms per {n} slices')
         if save:
             json.dump({k: v[0] for k, v in rep.items()}, open(save, 'w'), indent=1)
 
@@ -180,7 +190,7 @@ class Pipeline:
         nc = 1 if len(LABELS) == 1 else len(LABELS) + 1
         prob = torch.empty((hi - lo, nc, h, w), dtype=torch.float32, device=self.device)
         chk = torch.zeros((), dtype=torch.float64, device=self.device)
-        for s, x in dv.batches(axis, self.batch, lo, hi):
+        for s, x in dv.batches(axis, self.slices_per_call(h, w), lo, hi):
             if self.dtype != torch.float32:
                 x = x.to(self.dtype)
             out = self.model(x.contiguous(memory_format=torch.channels_last))
@@ -584,7 +594,7 @@ def main():
             'config': {'workload': f'stack (xy) inference, {D * world}x{S}x{S} uint8 volume, {MODELS[args.model]} '
                                    f'C={1 if len(LABELS) == 1 else len(LABELS) + 1} fp-forward on every slice + HIP post-processing on planted heads '
                                    f'(ks=7, full-res heads), {n_obj} planted objects per rank',
-                       'mode': 'stack', 'slices_per_rank': D, 'batch': args.batch,
+                       'mode': 'stack', 'slices_per_rank': D, 'batch': pipe.slices_per_call(S, S),
                        'objects_found': int(len(np.unique(host_out.numpy())) - 1)},
             'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'forward_end_to_slab_on_host': round(float(post_ms), 2),
                              'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2) if args.model == 'pdl_r50' and len(LABELS) == 1 else None,

@@ -310,6 +310,38 @@ def test_model_forward_with_hip_convolutions(force):
         assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (force, k, err, scale)
 
 
+@pytest.mark.parametrize('force', ['direct', 'wino4'])
+def test_model_forward_large_batch_equals_small_batches(force):
+    """128 slices of 512^2 in one model call (activations of 2^29 elements = 2 GiB and more: 32-bit byte offsets
+    would wrap) against the same slices in calls of 16.  The K-slab and tile choices depend on the grid size, so
+    the comparison is to rounding, not bit for bit."""
+    from empanada_amd.models import PanopticDeepLab, prepare_for_inference, synthesize_weights
+    from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
+    torch.manual_seed(1)
+    m = synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)).eval()
+    with torch.no_grad():
+        for head in (m.semantic_head, m.ins_center, m.ins_xy):
+            head.head[1].weight.mul_(1e-3)
+        g = prepare_for_inference(m, 'cuda')
+        x = torch.randn(128, 1, 512, 512, device='cuda').contiguous(memory_format=torch.channels_last)
+        g(x[:16])
+        n = 0
+        for mod in g.modules():
+            if isinstance(mod, FusedConvBNAct) and mod._seen is not None:
+                cand = mod.candidates(mod._seen[1])
+                mod.impl = force if force in cand else ('direct' if 'direct' in cand else 'miopen')
+                n += mod.impl != 'miopen'
+        assert n > 50
+        big = {k: v.float().cpu() for k, v in g(x).items()}
+        for s in range(0, 128, 16):
+            small = g(x[s:s + 16])
+            for k, v in small.items():
+                ref = v.float().cpu()
+                scale = max(1.0, float(ref.abs().max()))
+                err = float((big[k][s:s + 16] - ref).abs().max())
+                assert err <= 1e-4 * scale, (force, k, s, err, scale)
+
+
 @pytest.mark.parametrize('encoder,force', [('resnet50', 'direct'), ('resnet50', 'tuned'), ('regnety_6p4gf', 'direct')])
 def test_bifpn_forward_with_hip_convolutions(encoder, force):
     """D1, second model family (models/panoptic_bifpn.py:98-108): PanopticBiFPN through the same graph rewrite
