@@ -30,111 +30,113 @@ def logits_to_prob(logits):
     return torch.sigmoid(logits)
 
 
+def _on_gpu_f32(t):
+    """fp32 view of a head tensor on the GPU (the kernels take device pointers; there is no host path)"""
+    _hip.require_gpu()
+    return t.float() if t.is_cuda else t.float().cuda()
+
+
 class _Engine:
-    """engines.py:32-45"""
+    """Holds the model in eval mode (engines.py:32-45); subclasses define infer / __call__."""
 
     def __init__(self, model):
         self.model = model.eval()
 
+    def to_model_device(self, tensor):
+        return tensor.to(next(self.model.parameters()).device, non_blocking=True)
+
     def infer(self, image):
         raise NotImplementedError
-
-    def to_model_device(self, tensor):
-        device = next(self.model.parameters()).device
-        return tensor.to(device, non_blocking=True)
 
     def __call__(self, image):
         raise NotImplementedError
 
 
 class _MedianQueue:
-    """engines.py:47-90.  The deque holds the engine's output dicts; get_next(keys) overwrites the
-    middle item's tensors with the per-pixel median over the queue (emp_median_step), which makes
-    the filter recursive exactly like the reference."""
+    """Recursive median over the last ``median_kernel_size`` engine outputs (engines.py:47-90).
+
+    ``median_queue`` holds the output dicts of the most recent slices.  While it holds at most ks // 2 + 1 items the
+    newest one is handed out unfiltered; then nothing until the queue is full; from then on the item in the middle is
+    handed out AFTER its tensors under ``keys`` were replaced, in the queue itself, by the per-pixel median over the
+    whole queue (``emp_median_step``) -- later medians therefore see already-filtered values on their left side.
+    ``end()`` returns the ks // 2 items to the right of the middle, unfiltered."""
 
     def __init__(self, median_kernel_size, **kwargs):
         super().__init__(**kwargs)
         assert median_kernel_size % 2 == 1, "Kernel size must be odd integer!"
         assert median_kernel_size <= _hip.MAX_KS, f"median kernel sizes above {_hip.MAX_KS} are not supported"
         self.ks = median_kernel_size
-        self.mid_idx = (median_kernel_size - 1) // 2
-        self.median_queue = deque(maxlen=median_kernel_size)
+        self.mid_idx = median_kernel_size // 2
+        self.reset()
 
     def reset(self):
         self.median_queue = deque(maxlen=self.ks)
 
-    @torch.no_grad()
-    def get_median(self, key):
-        slices = [out[key] for out in self.median_queue]
-        _hip.require_gpu()
-        slices = [s.float().cuda() if not s.is_cuda else s.float() for s in slices]
-        return _hip.median_step(slices)
-
-    def get_next(self, keys):
-        nq = len(self.median_queue)
-        if nq <= self.mid_idx:
-            output = self.median_queue[-1]
-        elif nq < self.ks:
-            return None
-        else:
-            output = self.median_queue[self.mid_idx]
-            for key in keys:
-                output[key] = self.get_median(key)
-        return output
-
     def enqueue(self, item):
         self.median_queue.append(item)
 
+    @torch.no_grad()
+    def get_median(self, key):
+        return _hip.median_step([_on_gpu_f32(item[key]) for item in self.median_queue])
+
+    def get_next(self, keys):
+        held = len(self.median_queue)
+        if held == self.ks:
+            middle = self.median_queue[self.mid_idx]
+            middle.update({key: self.get_median(key) for key in keys})
+            return middle
+        return self.median_queue[-1] if held <= self.mid_idx else None
+
     def end(self):
-        return list(self.median_queue)[self.mid_idx + 1:]
+        return [item for pos, item in enumerate(self.median_queue) if pos > self.mid_idx]
+
+
+def _check_single_image(image):
+    assert image.ndim == 4 and image.size(0) == 1          # engines.py:144,203,306,369: one image per call
 
 
 class PanopticDeepLabEngine(_Engine):
-    """engines.py:92-159"""
+    """Full-resolution heads, one image per call -> panoptic labels (engines.py:92-159)."""
 
     def __init__(self, model, thing_list, label_divisor=1000, stuff_area=64, void_label=0, nms_threshold=0.1,
                  nms_kernel=7, confidence_thr=0.5, **kwargs):
         super().__init__(model=model)
-        self.thing_list = thing_list
-        self.label_divisor = label_divisor
-        self.stuff_area = stuff_area
-        self.void_label = void_label
-        self.nms_threshold = nms_threshold
-        self.nms_kernel = nms_kernel
+        self.thing_list, self.label_divisor = thing_list, label_divisor
+        self.stuff_area, self.void_label = stuff_area, void_label
+        self.nms_threshold, self.nms_kernel = nms_threshold, nms_kernel
         self.confidence_thr = confidence_thr
 
     @torch.no_grad()
     def _harden_seg(self, sem):
-        """engines.py:114-121 -> (N,1,H,W) int64 (emp_harden)."""
-        _hip.require_gpu()
-        sem = sem.float().cuda() if not sem.is_cuda else sem.float()
+        """probabilities (N,C,H,W) -> class map (N,1,H,W) int64: argmax over C > 1 channels, ``p >= confidence_thr``
+        for C = 1 (engines.py:114-121; emp_harden)."""
+        sem = _on_gpu_f32(sem)
         N, C, H, W = sem.shape
-        out = torch.empty((N, H, W), dtype=torch.uint8, device=sem.device)
+        hard = torch.empty((N, H, W), dtype=torch.uint8, device=sem.device)
         for n in range(N):
-            one = sem[n:n + 1].contiguous()
-            _hip.call('emp_harden', one.data_ptr(), 1, C, H * W, float(self.confidence_thr),
-                      out[n].data_ptr(), _hip.stream())
-        return out[:, None].long()
+            plane = sem[n:n + 1].contiguous()
+            _hip.call('emp_harden', plane.data_ptr(), 1, C, H * W, float(self.confidence_thr), hard[n].data_ptr(),
+                      _hip.stream())
+        return hard[:, None].long()
 
     @torch.no_grad()
     def infer(self, image):
-        model_out = self.model(image)
-        model_out['sem'] = logits_to_prob(model_out['sem_logits'])   # notice that sem is NOT sem_logits
-        return model_out
+        """model outputs plus 'sem' = class probabilities (the logits stay under 'sem_logits'), engines.py:123-129"""
+        heads = self.model(image)
+        heads['sem'] = logits_to_prob(heads['sem_logits'])
+        return heads
 
     @torch.no_grad()
     def postprocess(self, sem, ctr_hmp, offsets):
-        pan_seg, _ = get_panoptic_segmentation(
-            sem, ctr_hmp, offsets, self.thing_list, self.label_divisor, self.stuff_area, self.void_label,
-            self.nms_threshold, self.nms_kernel)
-        return pan_seg
+        return get_panoptic_segmentation(sem, ctr_hmp, offsets, self.thing_list, self.label_divisor, self.stuff_area,
+                                         self.void_label, self.nms_threshold, self.nms_kernel)[0]
+
+    def _labels_of(self, heads):
+        return self.postprocess(self._harden_seg(heads['sem']), heads['ctr_hmp'], heads['offsets'])
 
     def __call__(self, image):
-        assert image.ndim == 4 and image.size(0) == 1
-        image = self.to_model_device(image)
-        model_out = self.infer(image)
-        model_out['sem'] = self._harden_seg(model_out['sem'])
-        return self.postprocess(model_out['sem'], model_out['ctr_hmp'], model_out['offsets'])
+        _check_single_image(image)
+        return self._labels_of(self.infer(self.to_model_device(image)))
 
     # ---- MI355X-native whole-stack path ----------------------------------------------------
     def _stack_params(self):
@@ -162,7 +164,8 @@ class PanopticDeepLabEngine(_Engine):
 
 
 class PanopticDeepLabEngine3d(_MedianQueue, PanopticDeepLabEngine):
-    """engines.py:161-221"""
+    """PanopticDeepLabEngine behind the recursive median queue: ``engine(image)`` returns None while the queue
+    fills, ``end()`` flushes the last ks // 2 slices (engines.py:161-221)."""
 
     def __init__(self, model, thing_list, label_divisor=1000, stuff_area=64, void_label=0, nms_threshold=0.1,
                  nms_kernel=7, confidence_thr=0.5, median_kernel_size=3, **kwargs):
@@ -170,26 +173,23 @@ class PanopticDeepLabEngine3d(_MedianQueue, PanopticDeepLabEngine):
                          void_label=void_label, nms_threshold=nms_threshold, nms_kernel=nms_kernel,
                          confidence_thr=confidence_thr, median_kernel_size=median_kernel_size, **kwargs)
 
-    def end(self):
-        final_segs = []
-        for model_out in list(self.median_queue)[self.mid_idx + 1:]:
-            model_out['sem'] = self._harden_seg(model_out['sem'])
-            final_segs.append(self.postprocess(model_out['sem'], model_out['ctr_hmp'], model_out['offsets']))
-        return final_segs
-
     def __call__(self, image):
-        assert image.ndim == 4 and image.size(0) == 1
-        image = self.to_model_device(image)
-        model_out = self.infer(image)
-        self.enqueue(model_out)
-        median_out = self.get_next(keys=['sem'])
-        if median_out is None:
-            return None
-        return self.postprocess(self._harden_seg(median_out['sem']), median_out['ctr_hmp'], median_out['offsets'])
+        _check_single_image(image)
+        self.enqueue(self.infer(self.to_model_device(image)))
+        ready = self.get_next(keys=['sem'])
+        return None if ready is None else self._labels_of(ready)
+
+    def end(self):
+        tail = _MedianQueue.end(self)
+        for heads in tail:                                 # the reference leaves the hardened map in the queue item
+            heads['sem'] = self._harden_seg(heads['sem'])
+        return [self.postprocess(heads['sem'], heads['ctr_hmp'], heads['offsets']) for heads in tail]
 
 
 class PanopticDeepLabRenderEngine(PanopticDeepLabEngine):
-    """engines.py:223-325"""
+    """PointRend models: instance heads at 1/4 resolution (``coarse_boundaries``), semantic head rendered at
+    ``upsampling`` x the input; images are padded to ``padding_factor`` and the result cropped back to ``size``
+    (engines.py:223-325)."""
 
     def __init__(self, model, thing_list, label_divisor=1000, stuff_area=64, void_label=0, nms_threshold=0.1,
                  nms_kernel=7, confidence_thr=0.5, padding_factor=16, coarse_boundaries=True, **kwargs):
@@ -201,46 +201,50 @@ class PanopticDeepLabRenderEngine(PanopticDeepLabEngine):
 
     @torch.no_grad()
     def infer(self, image, render_steps=2):
-        model_out = self.model(image, render_steps, interpolate_ins=not self.coarse_boundaries)
-        model_out['sem'] = logits_to_prob(model_out['sem_logits'])
-        return model_out
+        heads = self.model(image, render_steps, interpolate_ins=not self.coarse_boundaries)
+        heads['sem'] = logits_to_prob(heads['sem_logits'])
+        return heads
 
     @torch.no_grad()
     def get_instance_cells(self, ctr_hmp, offsets, upsampling=1):
-        """engines.py:257-275 -> (1,1,H,W) fp32 cells."""
-        ctr = find_instance_center(ctr_hmp, self.nms_threshold, self.nms_kernel)
+        """centre NMS + nearest-centre vote on the (possibly 1/4-resolution) instance heads, enlarged by nearest
+        neighbour to the resolution of the semantic map -> (1,1,H,W) fp32 ids, 0 everywhere without centres
+        (engines.py:257-275)."""
         step = 4 if self.coarse_boundaries else 1
-        if ctr.size(0) == 0:
-            instance_cells = torch.zeros_like(ctr_hmp.cuda() if not ctr_hmp.is_cuda else ctr_hmp)
+        centres = find_instance_center(ctr_hmp, self.nms_threshold, self.nms_kernel)
+        if centres.size(0) > 0:
+            cells = group_pixels(centres, offsets, step=step).float()[None]
         else:
-            instance_cells = group_pixels(ctr, offsets, step=step).float()[None]
-        return F.interpolate(instance_cells, scale_factor=int(upsampling * step), mode='nearest')
+            cells = torch.zeros_like(ctr_hmp if ctr_hmp.is_cuda else ctr_hmp.cuda())
+        return F.interpolate(cells, scale_factor=int(upsampling * step), mode='nearest')
 
     @torch.no_grad()
     def get_panoptic_seg(self, sem, instance_cells):
-        """engines.py:277-292"""
-        instance_seg = torch.zeros_like(sem)
-        for thing_class in self.thing_list:
-            instance_seg[sem == thing_class] = 1
-        instance_seg = (instance_seg * instance_cells[0]).long()
-        return merge_semantic_and_instance(sem, instance_seg, self.label_divisor, self.thing_list, self.stuff_area,
+        """cells masked to the thing classes, then the majority-class fusion (engines.py:277-292)"""
+        is_thing = torch.zeros_like(sem)
+        for cls in self.thing_list:
+            is_thing[sem == cls] = 1
+        ids = (is_thing * instance_cells[0]).long()
+        return merge_semantic_and_instance(sem, ids, self.label_divisor, self.thing_list, self.stuff_area,
                                            self.void_label)
 
     @torch.no_grad()
     def postprocess(self, sem, instance_cells):
-        sem = self._harden_seg(sem)[0]
-        return self.get_panoptic_seg(sem, instance_cells)
+        return self.get_panoptic_seg(self._harden_seg(sem)[0], instance_cells)
+
+    def _padded_heads(self, image, upsampling):
+        """pad, move to the model's device, forward with 2 + log2(upsampling) render steps"""
+        extra = math.log(upsampling, 2)
+        assert extra.is_integer(), "Upsampling factor not log base 2!"
+        _check_single_image(image)
+        return self.infer(self.to_model_device(factor_pad(image, self.padding_factor)), int(2 + extra))
+
+    def _cropped_labels(self, heads, size, upsampling):
+        cells = self.get_instance_cells(heads['ctr_hmp'], heads['offsets'], upsampling)
+        return self.postprocess(heads['sem'], cells)[..., :size[0], :size[1]]
 
     def __call__(self, image, size, upsampling=1):
-        assert math.log(upsampling, 2).is_integer(), "Upsampling factor not log base 2!"
-        assert image.ndim == 4 and image.size(0) == 1
-        h, w = size
-        image = factor_pad(image, self.padding_factor)
-        image = self.to_model_device(image)
-        model_out = self.infer(image, int(2 + math.log(upsampling, 2)))
-        instance_cells = self.get_instance_cells(model_out['ctr_hmp'], model_out['offsets'], upsampling)
-        pan_seg = self.postprocess(model_out['sem'], instance_cells)
-        return pan_seg[..., :h, :w]
+        return self._cropped_labels(self._padded_heads(image, upsampling), size, upsampling)
 
     @torch.no_grad()
     def postprocess_stack(self, heads, upsampling=1):
@@ -249,7 +253,8 @@ class PanopticDeepLabRenderEngine(PanopticDeepLabEngine):
 
 
 class PanopticDeepLabRenderEngine3d(_MedianQueue, PanopticDeepLabRenderEngine):
-    """engines.py:327-394"""
+    """PanopticDeepLabRenderEngine behind the recursive median queue; every queue item remembers the ``size`` it
+    must be cropped to (engines.py:327-394)."""
 
     def __init__(self, model, thing_list, label_divisor=1000, stuff_area=64, void_label=0, nms_threshold=0.1,
                  nms_kernel=7, confidence_thr=0.5, median_kernel_size=3, padding_factor=16, coarse_boundaries=True,
@@ -259,29 +264,15 @@ class PanopticDeepLabRenderEngine3d(_MedianQueue, PanopticDeepLabRenderEngine):
                          confidence_thr=confidence_thr, median_kernel_size=median_kernel_size,
                          padding_factor=padding_factor, coarse_boundaries=coarse_boundaries)
 
-    def end(self, upsampling=1):
-        final_segs = []
-        for model_out in list(self.median_queue)[self.mid_idx + 1:]:
-            h, w = model_out['size']
-            cells = self.get_instance_cells(model_out['ctr_hmp'], model_out['offsets'], upsampling)
-            final_segs.append(self.postprocess(model_out['sem'], cells)[..., :h, :w])
-        return final_segs
-
     def __call__(self, image, size, upsampling=1):
-        assert math.log(upsampling, 2).is_integer(), "Upsampling factor not log base 2!"
-        assert image.ndim == 4 and image.size(0) == 1
-        h, w = size
-        image = factor_pad(image, self.padding_factor)
-        image = self.to_model_device(image)
-        model_out = self.infer(image, int(2 + math.log(upsampling, 2)))
-        model_out['size'] = size
-        self.enqueue(model_out)
-        median_out = self.get_next(keys=['sem'])
-        if median_out is None:
-            return None
-        cells = self.get_instance_cells(median_out['ctr_hmp'], median_out['offsets'], upsampling)
-        pan_seg = self.postprocess(median_out['sem'], cells)
-        return pan_seg[..., :h, :w]
+        heads = self._padded_heads(image, upsampling)
+        heads['size'] = size
+        self.enqueue(heads)
+        ready = self.get_next(keys=['sem'])
+        return None if ready is None else self._cropped_labels(ready, ready['size'], upsampling)
+
+    def end(self, upsampling=1):
+        return [self._cropped_labels(heads, heads['size'], upsampling) for heads in _MedianQueue.end(self)]
 
 
 class MultiGPUInferenceEngine(PanopticDeepLabRenderEngine):
