@@ -1,0 +1,61 @@
+"""HIP-graph replay of an inference model's forward, for the launch-bound case.
+
+The whole-stack protocol pushes 128 slices through the model per call: ~350 kernels of ~0.5 ms each, the queue never
+runs dry and a graph would buy nothing.  The reference's own scripts, however, call ``engine(image)`` once per slice
+(scripts/pdl_inference3d.py:140-160): at batch 1 the forward is ~200 launches of 5-20 us behind several hundred
+Python module calls, and the GPU idles between them.  ``GraphedForward`` captures the forward once per input shape
+(hipStreamBeginCapture through ``torch.cuda.graph``; the hand-written kernels are launched on torch's current stream,
+so they are captured like torch's own) and replays it with a single launch afterwards.
+
+Outputs are cloned out of the graph's static buffers, because the engines keep the head tensors of the last
+``median_kernel_size`` slices in their queue.
+"""
+import torch
+
+__all__ = ['GraphedForward']
+
+
+class GraphedForward(torch.nn.Module):
+    """``model = GraphedForward(prepare_for_inference(model))``; call it like the model.  One graph per distinct
+    (input shape, dtype, extra positional / keyword arguments); inputs must live on the model's GPU."""
+
+    def __init__(self, model, warmup=3, max_graphs=8):
+        super().__init__()
+        self.model = model.eval()
+        self.warmup = int(warmup)
+        self.max_graphs = int(max_graphs)
+        self._graphs = {}
+
+    def parameters(self, recurse=True):              # engines look the device up through the first parameter
+        return self.model.parameters(recurse)
+
+    @torch.no_grad()
+    def _capture(self, x, args, kwargs):
+        static_in = x.clone()
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                # warm-up off the capture: MIOpen find, filter transforms, tile tables
+            for _ in range(self.warmup):
+                self.model(static_in, *args, **kwargs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = self.model(static_in, *args, **kwargs)
+        return graph, static_in, static_out
+
+    @torch.no_grad()
+    def forward(self, x, *args, **kwargs):
+        if not x.is_cuda:
+            raise RuntimeError("GraphedForward needs its input on the GPU")
+        key = (tuple(x.shape), x.dtype, x.is_contiguous(memory_format=torch.channels_last), args,
+               tuple(sorted(kwargs.items())))
+        entry = self._graphs.get(key)
+        if entry is None:
+            if len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = self._graphs[key] = self._capture(x, args, kwargs)
+        graph, static_in, static_out = entry
+        static_in.copy_(x)
+        graph.replay()
+        return {k: v.clone() for k, v in static_out.items()}

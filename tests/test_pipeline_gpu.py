@@ -310,6 +310,40 @@ def test_model_forward_with_hip_convolutions(force):
         assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (force, k, err, scale)
 
 
+def test_graphed_forward_replays_the_model():
+    """models/graphed.py: the batch-1 forward captured as a HIP graph (hand-written kernels + MIOpen in one capture)
+    returns what the eager forward returns, for fresh inputs, a second shape, and outputs that stay valid after later
+    replays (the engines keep them in the median queue).  Two eager runs of the same input already differ in the last
+    bit at batch 1 (MIOpen picks split-K kernels with atomic accumulation for the stem), so the comparison allows
+    1e-6 * max(1, |x|_inf); a stale or missing node in the graph would be off by orders of magnitude."""
+    from empanada_amd.models import GraphedForward, PanopticDeepLab, prepare_for_inference, synthesize_weights
+    from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
+    torch.manual_seed(3)
+    m = synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)).eval()
+    with torch.no_grad():
+        for head in (m.semantic_head, m.ins_center, m.ins_xy):
+            head.head[1].weight.mul_(1e-3)
+        net = prepare_for_inference(m, 'cuda')
+        xs = [torch.randn(1, 1, 256, 256, device='cuda').contiguous(memory_format=torch.channels_last) for _ in range(3)]
+        xs.append(torch.randn(2, 1, 128, 192, device='cuda').contiguous(memory_format=torch.channels_last))
+        net(xs[0])
+        n = 0
+        for mod in net.modules():                      # a mix of implementations inside one capture
+            if isinstance(mod, FusedConvBNAct) and mod._seen is not None:
+                cand = mod.candidates(mod._seen[1])
+                mod.impl = ('wino4' if 'wino4' in cand else 'direct' if 'direct' in cand else 'miopen') if n % 3 else 'miopen'
+                n += 1
+        eager = [{k: v.clone() for k, v in net(x).items()} for x in xs]
+        graphed = GraphedForward(net)
+        outs = [graphed(x) for x in xs] + [graphed(xs[0])]
+        assert len(graphed._graphs) == 2
+        for got, exp in zip(outs, eager + [eager[0]]):
+            for k in exp:
+                err = float((got[k] - exp[k]).abs().max())
+                assert err <= 1e-6 * max(1.0, float(exp[k].abs().max())), (k, err)
+        assert next(graphed.parameters()).is_cuda
+
+
 @pytest.mark.parametrize('force', ['direct', 'wino4'])
 def test_model_forward_large_batch_equals_small_batches(force):
     """128 slices of 512^2 in one model call (activations of 2^29 elements = 2 GiB and more: 32-bit byte offsets

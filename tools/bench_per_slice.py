@@ -1,0 +1,110 @@
+"""Throughput of the DROP-IN per-slice protocol -- the calls scripts/pdl_inference3d.py:140-233 makes, one slice at a
+time: engine(image) -> pan_seg_to_rle_seg -> apply_matchers, then engine.end(), backward_matching + update_trackers,
+finish, filters, fill -- next to the whole-stack protocol bench.py times.  The model forward runs on every slice
+(batch 1, timed); its outputs are replaced by the planted heads of that slice so that the post-processing sees a
+realistic object load (same convention as bench.py).
+usage: PYTHONPATH=. python tools/bench_per_slice.py [n_slices] [plain|tuned|graph]"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+import bench
+from empanada_amd.inference import engines as EN
+from empanada_amd.inference import filters
+from empanada_amd.inference import patterns as PA
+from empanada_amd.inference import rle
+from empanada_amd.models import GraphedForward, prepare_for_inference, tune_fused_convs
+
+
+class PlantedModel(torch.nn.Module):
+    """runs the real network, hands back the planted head tensors of the current slice"""
+
+    def __init__(self, net, heads):
+        super().__init__()
+        self.net, self.heads, self.t = net, heads, 0
+        self.checksum = torch.zeros((), dtype=torch.float64, device='cuda')
+
+    def forward(self, x):
+        out = self.net(x.contiguous(memory_format=torch.channels_last))
+        self.checksum += out['sem_logits'].float().sum(dtype=torch.float64)
+        t, self.t = self.t, self.t + 1
+        p = self.heads['sem'][t:t + 1].clamp(1e-6, 1 - 1e-6)
+        return {'sem_logits': torch.log(p / (1 - p)), 'ctr_hmp': self.heads['ctr_hmp'][t:t + 1],
+                'offsets': self.heads['offsets'][t:t + 1]}
+
+
+def main():
+    D = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    S = 512
+    dev = torch.device('cuda')
+    vol, heads, n_obj = bench.build_inputs(D, S, dev)
+    net = prepare_for_inference(bench.build_model('pdl_r50'), dev)
+    mode = sys.argv[2] if len(sys.argv) > 2 else 'plain'            # plain | tuned | graph (= tuned + HIP graph)
+    if mode in ('tuned', 'graph'):
+        x1 = torch.rand((1, 1, S, S), device=dev).contiguous(memory_format=torch.channels_last)
+        rep = tune_fused_convs(net, x1)
+        counts = {}
+        for best, _ in rep.values():
+            counts[best] = counts.get(best, 0) + 1
+        print('conv sites at batch 1:', counts)
+    if mode == 'graph':
+        net = GraphedForward(net)
+    model = PlantedModel(net, heads).eval()
+    labels, thing, div = [1], bench.ENGINE['thing_list'], bench.ENGINE['label_divisor']
+    images = [vol.batch('xy', t, t + 1) for t in range(D)]          # normalised (1,1,H,W) slices, resident
+    stages = {}
+
+    def tick(name, t0):
+        torch.cuda.synchronize()
+        stages[name] = stages.get(name, 0.0) + time.perf_counter() - t0
+
+    for rep in range(2):                                             # pass 0 warms MIOpen / allocator up
+        model.t = 0
+        stages.clear()
+        eng = EN.PanopticDeepLabEngine3d(model, **bench.ENGINE)
+        matchers = PA.create_matchers(thing, div, bench.MATCH['merge_iou_thr'], bench.MATCH['merge_ioa_thr'])
+        trackers = PA.create_axis_trackers({'xy': 0}, labels, div, (D, S, S))['xy']
+        torch.cuda.synchronize()
+        t_all = time.perf_counter()
+        stack = []
+        for t in range(D):
+            t0 = time.perf_counter()
+            pan = eng(images[t])
+            tick('engine (forward + median + pixels)', t0)
+            if pan is None:
+                continue
+            t0 = time.perf_counter()
+            seg = rle.pan_seg_to_rle_seg(pan.squeeze().cpu().numpy(), labels, div, thing, True)
+            tick('pan_seg_to_rle_seg', t0)
+            t0 = time.perf_counter()
+            stack.append(PA.apply_matchers(seg, matchers))
+            tick('forward matching', t0)
+        t0 = time.perf_counter()
+        for pan in eng.end():
+            seg = rle.pan_seg_to_rle_seg(pan.squeeze().cpu().numpy(), labels, div, thing, True)
+            stack.append(PA.apply_matchers(seg, matchers))
+        tick('engine.end + tail', t0)
+        t0 = time.perf_counter()
+        for idx, rs in PA.backward_matching(stack, matchers, len(stack)):
+            PA.update_trackers(rs, idx, trackers)
+        PA.finish_tracking(trackers)
+        for tr in trackers:
+            filters.remove_small_objects(tr, min_size=bench.FILTERS['min_size'])
+            filters.remove_pancakes(tr, min_span=bench.FILTERS['min_span'])
+        tick('backward matching + trackers + filters', t0)
+        t0 = time.perf_counter()
+        out = np.zeros((D, S, S), dtype=np.uint32)
+        for tr in trackers:
+            PA.fill_volume(out, tr.instances)
+        tick('fill', t0)
+        dt = time.perf_counter() - t_all
+    print(f'per-slice protocol ({mode}), {D}x{S}x{S}: {D * S * S / dt / 1e6:.2f} Mvox/s ({dt / D * 1e3:.2f} ms / slice), '
+          f'{len(stack)} slices emitted, {sum(len(t.instances) for t in trackers)} objects')
+    for k, v in stages.items():
+        print(f'  {k:42s} {v:7.3f} s  {100 * v / dt:5.1f} %')
+
+
+if __name__ == '__main__':
+    main()
