@@ -24,10 +24,15 @@ class PlantedModel(torch.nn.Module):
     def __init__(self, net, heads):
         super().__init__()
         self.net, self.heads, self.t = net, heads, 0
+        self.events = []
         self.checksum = torch.zeros((), dtype=torch.float64, device='cuda')
 
     def forward(self, x):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         out = self.net(x.contiguous(memory_format=torch.channels_last))
+        e1.record()
+        self.events.append((e0, e1))
         self.checksum += out['sem_logits'].float().sum(dtype=torch.float64)
         t, self.t = self.t, self.t + 1
         p = self.heads['sem'][t:t + 1].clamp(1e-6, 1 - 1e-6)
@@ -62,6 +67,7 @@ def main():
 
     for rep in range(2):                                             # pass 0 warms MIOpen / allocator up
         model.t = 0
+        model.events = []
         stages.clear()
         eng = EN.PanopticDeepLabEngine3d(model, **bench.ENGINE)
         matchers = PA.create_matchers(thing, div, bench.MATCH['merge_iou_thr'], bench.MATCH['merge_ioa_thr'])
@@ -102,6 +108,8 @@ def main():
         dt = time.perf_counter() - t_all
     print(f'per-slice protocol ({mode}), {D}x{S}x{S}: {D * S * S / dt / 1e6:.2f} Mvox/s ({dt / D * 1e3:.2f} ms / slice), '
           f'{len(stack)} slices emitted, {sum(len(t.instances) for t in trackers)} objects')
+    fwd = sum(a.elapsed_time(b) for a, b in model.events) * 1e-3
+    print(f'  of the engine time, model forward (HIP events): {fwd:.3f} s = {fwd / D * 1e3:.2f} ms / slice')
     for k, v in stages.items():
         print(f'  {k:42s} {v:7.3f} s  {100 * v / dt:5.1f} %')
 
