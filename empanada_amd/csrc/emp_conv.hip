@@ -524,10 +524,14 @@ struct CgPlan {
     int slab, tiles_m, tiles_n;
 };
 
-static CgPlan cg_plan(int64_t M, int Cout, int batch, bool has_res, bool res_vec_ok)
+static CgPlan cg_plan(int64_t M, int Cout, int batch, bool has_res, bool res_vec_ok, bool may_split_n = true)
 {
     CgPlan p;
-    p.narrow = Cout <= 64 || (Cout % 128 != 0 && Cout % 128 <= 64 && Cout < 512);
+    // 64-wide cout tiles for narrow layers, and whenever 128-wide tiles would leave CUs without a block (small
+    // launches: the per-slice protocol at batch 1 has 8-64 pixel tiles in layer3 / layer4).  The K order, hence the
+    // summation order, does not depend on the cout tiling.
+    const int64_t wide_blocks = emp_cdiv(M, CG_BM) * emp_cdiv(Cout, 128) * batch;
+    p.narrow = Cout <= 64 || (Cout % 128 != 0 && Cout % 128 <= 64 && Cout < 512) || (may_split_n && wide_blocks < 256);
     p.tiles_m = (int)emp_cdiv(M, CG_BM);
     p.tiles_n = (int)emp_cdiv(Cout, p.narrow ? 64 : 128);
     p.respf = has_res && res_vec_ok && Cout % (p.narrow ? 64 : 128) == 0;
@@ -620,7 +624,7 @@ extern "C" int emp_conv_bn_act_proj_nhwc(const float *x, const float *w_okkc, co
     g.M = (int64_t)N * OH * OW; g.out_ps = out_pixel_stride; g.res_ps = Cout;
     g.x_bs = g.w_bs = g.out_bs = 0; g.tiles = nullptr;
     g.proj_w = proj_w; g.proj_out = proj_out; g.proj_n = proj_n; g.hw = (int64_t)OH * OW;
-    const CgPlan pl = cg_plan(g.M, Cout, 1, false, true);
+    const CgPlan pl = cg_plan(g.M, Cout, 1, false, true, false);      // the fold needs whole 128-wide cout tiles
     g.tiles_m = pl.tiles_m;
     g.tiles_n = pl.tiles_n;
     const int T = g.tiles_m * g.tiles_n;
