@@ -397,10 +397,13 @@ extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr
 }
 
 // ------------------------------------------------------------------------------------------
-// P4: nearest-centre vote.  Block = 256 threads x GP_PPT pixels of one slice; the slice's centres
-// sit in LDS (broadcast reads).  Exact rounding contract (see emp_hip.h):
+// P4: nearest-centre vote.  Block = GP_THREADS threads x GP_PER_THREAD pixels of one slice; the slice's centres
+// (pre-scaled float2, padded with +inf) are read with wave-uniform indices, i.e. as scalar loads.  Exact rounding
+// contract (see emp_hip.h):
 //   s = fmaf(dx, dx, fl(dy*dy)); d = sqrt_rn(s); first strictly smaller d wins.
-// sqrt is monotone, so d is only evaluated when s improves on the best s so far.
+// sqrt is monotone, so the comparison runs on s and d is only evaluated for near ties.
+// (A per-block pruning of the centre list by the bounding box of the voted locations was tried and removed: a tile
+// is two image rows, its box spans the slice and prunes nothing; the kernel is 0.2 % of a pass.)
 // Work compaction: a block owns GP_TILE consecutive pixels.  Pixels that need a vote (all of them without a
 // semantic map, only thing pixels with one -- ~10 % of an EM slice) are compacted into an LDS list so that the
 // K-centre loop runs with full lanes; ids are staged in LDS and written back as one coalesced 16-byte store
