@@ -19,18 +19,17 @@ import numpy as np
 import torch
 import torch.distributed as dist
 from scipy.optimize import linear_sum_assignment
-from scipy.sparse import coo_matrix
 
 from .. import _hip
-from ..array_utils import merge_boxes, numpy_fill_instances, put
+from ..array_utils import merge_boxes, numpy_fill_instances
 from ..consensus import merge_objects_from_trackers, merge_semantic_from_trackers
 from ..zarr_utils import zarr_fill_instances
 from . import filters
 from .engines import _MedianQueue
-from .matcher import RLEMatcher, assign_labels
+from .matcher import RLEMatcher
 from .postprocess import merge_semantic_and_instance
-from .rle import pan_seg_to_rle_seg, rle_seg_to_pan_seg, runs_to_instances
-from .tracker import InstanceTracker, to_box3d
+from .rle import pan_seg_to_rle_seg
+from .tracker import InstanceTracker
 
 __all__ = [
     'create_matchers', 'create_axis_trackers', 'apply_matchers', 'forward_matching', 'backward_matching',
