@@ -2,25 +2,33 @@
 """bench.py -- end-to-end 3D panoptic inference throughput on MI355X (Mvox/s).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).
-A "step" is one full pass of the hot path over one synthetic volume: model forward over every slice
-(PyTorch-ROCm, fp32, the named architecture with synthesised weights) -> sigmoid -> recursive median +
-harden -> centres -> pixel grouping -> semantic/instance fusion -> runs + 8-connected components ->
-slice-to-slice overlaps -> forward/backward label propagation -> trackers -> size/span filters -> labelled
-uint32 volume written to (pinned) host memory.
 
-Workload at N=1 = BASELINE.json configs[1]: single-GPU stack inference, 256x512x512 volume, ResNet-50 encoder.
+Default workload (the configuration BASELINE.json's metric is quoted on): ORTHOPLANE inference + consensus on a
+1024^3 uint8 volume -- the volume of configs[3], which fits one MI355X; `--size 512` is configs[2].  A "step" is one
+full pass of the hot path over the volume (scripts/pdl_inference3d.py:110-233 in orthoplane mode):
+  for each plane xy / xz / yz: PanopticDeepLab-R50 forward over every slice (fp32, synthesised weights, resident uint8
+  volume) -> sigmoid -> recursive median + harden -> centres -> pixel grouping -> semantic/instance fusion -> runs +
+  8-connected components -> slice-to-slice overlaps -> forward/backward label propagation -> 3D trackers -> size/span
+  filters;  then instance consensus over the three planes -> filters -> labelled uint32 volume in pinned host memory.
+`--mode stack` keeps round 1's xy-only stack workload (configs[1], 256x512x512, no consensus).
+
 Inputs are resident in HBM when the timed region starts (uint8 EM volume + planted head tensors, see
-empanada_amd/synthetic.py and DESIGN.md "Synthetic workload": the conv forward is computed and timed on every
-slice, its outputs are checksummed, and the post-processing consumes the planted heads so that it sees a
-realistic object load; random weights would give it an empty or degenerate segmentation).
+empanada_amd/synthetic.py and DESIGN.md "Synthetic workload": the conv forward is computed and timed on every slice
+of every plane and checksummed, and checked after the timed region against a CPU forward of the same weights; the
+post-processing consumes the planted heads so that it sees a realistic object load -- random weights would give it
+an empty or degenerate segmentation).
 
-N>1 (launched by torch.distributed.run, one rank per GPU, RCCL): the volume's depth grows with N (weak
-scaling, 256 slices per rank); see DESIGN.md "Multi-GPU".
+N > 1: `--gpus N` starts N ranks itself (a `torch.distributed.run` child process, before this process touches the
+GPU) unless it already runs under one (WORLD_SIZE set: the driver's launch line).  One rank per GPU, RCCL; every plane's
+slices are split into contiguous blocks over the ranks of ONE shared volume (strong scaling); see DESIGN.md
+"Multi-GPU".
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -34,7 +42,9 @@ ENGINE = dict(thing_list=[1], label_divisor=20000, stuff_area=64, void_label=0, 
 LABELS = [1]                                                  # --things T: classes 1..T, all of them things
 MATCH = dict(merge_iou_thr=0.25, merge_ioa_thr=0.25)
 FILTERS = dict(min_size=500, min_span=4)
+CONSENSUS = dict(pixel_vote_thr=2, cluster_iou_thr=0.75, bypass=False)      # scripts/pdl_inference3d.py:44-47
 NORM = dict(mean=0.508979, std=0.148561)                      # MitoNet norms
+METRIC = 'Mvox/s end-to-end 3D panoptic inference (incl. consensus); PQ vs CPU ref'
 # Algorithmic HBM bytes per voxel of the single-kernel ABI calls, C = 1, full-res heads.
 # f = fraction of voxels whose class is a thing (measured on the run's own data): only those read offsets.
 ALG_BYTES = {
@@ -45,36 +55,40 @@ ALG_BYTES = {
     'emp_runs_count': lambda f: 4,                     # read pan
     'emp_runs_extract': lambda f: 4,                   # read pan (+12 B per run)
 }
-# HBM traffic per voxel from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, calibrated on known byte counts;
-# profiles/r1_pmc_postproc_256x512x512.md), same workload.  Collected offline: --pmc cannot run inside this script.
-PMC_TRAFFIC_BYTES_PER_VOXEL = {
-    'emp_median_harden_stack': 5.02, 'emp_find_centers': 4.56, 'emp_group_pixels': 4.60, 'emp_fuse_apply': 7.01,
-    'emp_runs_count': 4.02, 'emp_runs_extract': 4.15,
-}
-# same, as a ratio to the algorithmic bytes, for the dense-path kernels whose shapes vary from call to call
-# (profiles/r1_pmc_dense.md)
+# HBM traffic / algorithmic bytes from rocprofv3 PMC passes over this script (2 x FETCH_SIZE + WRITE_SIZE, calibrated
+# on known byte counts), collected OFFLINE with the tuned implementation choices replayed: --pmc cannot run inside this
+# script.  The JSON line labels the figure `traffic_source: offline PMC`.
 PMC_TRAFFIC_RATIO = {
-    # HBM traffic (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes, averaged over the launches of a timed pass with
-    # the tuned implementation choices replayed (--load-tune): profiles/r1_pmc_bench_dense.md
     'emp_conv_bn_act_nhwc': 1.18, 'emp_bn_act_nhwc': 1.0, 'emp_dwconv_nhwc': 1.06, 'emp_upsample_bilinear': 1.2,
+    'emp_median_harden_stack': 1.0, 'emp_find_centers': 1.14, 'emp_group_pixels': 1.26, 'emp_fuse_apply': 1.0,
+    'emp_runs_count': 1.0, 'emp_runs_extract': 1.04,
 }
+PMC_SOURCE = 'offline PMC ratio x algorithmic bytes (profiles/r1_pmc_bench_dense.md, r1_pmc_postproc_256x512x512.md)'
 DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 'emp_conv_bn_act_nhwc',
-                 'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
-                 'emp_wino_output_transform', 'emp_wino4_input_transform', 'emp_wino4_output_transform', 'emp_wino3_input_transform',
-                 'emp_wino3_output_transform',
+                 'emp_conv_bn_act_proj_nhwc', 'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
+                 'emp_wino_output_transform', 'emp_wino4_input_transform', 'emp_wino4_output_transform',
+                 'emp_wino3_input_transform', 'emp_wino3_output_transform',
                  'emp_pointwise_out_nhwc', 'emp_bn_relu_maxpool_nhwc', 'emp_slices_to_input')
-MFMA_KERNELS = ('emp_conv_bn_act_nhwc', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused')
+MFMA_KERNELS = ('emp_conv_bn_act_nhwc', 'emp_conv_bn_act_proj_nhwc', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused')
 MFMA_F32_PEAK_TFLOPS = 157.3                   # dense fp32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FLOPS_PER_VOXEL_PDL_R50 = 414477.0             # PanopticDeepLab-R50, C = 1, per input pixel
+
+# --model name -> label in config.workload (the FLOP count above is only known for the headline model)
+MODELS = {'pdl_r50': 'PanopticDeepLab/ResNet-50', 'bifpn_r50': 'PanopticBiFPN/ResNet-50',
+          'bifpn_regnety': 'PanopticBiFPN/RegNetY-6.4GF'}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=None, help='timed passes (default: 3 orthoplane, 10 stack)')
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--depth', type=int, default=256, help='slices per rank')
-    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--mode', default='orthoplane', choices=['orthoplane', 'stack'],
+                    help='orthoplane = xy/xz/yz + consensus on a cubic volume of side --size (the metric\'s '
+                         'configuration); stack = BASELINE configs[1] (xy only, --depth x --size x --size)')
+    ap.add_argument('--size', type=int, default=None, help='default: 1024 (orthoplane) / 512 (stack)')
+    ap.add_argument('--depth', type=int, default=256, help='stack mode: slices per rank')
     ap.add_argument('--batch', type=int, default=128,
                     help='slices of 512 x 512 per model call; larger slices get proportionally fewer per call '
                          '(same pixels per call: the largest activations stay at 2 GiB)')
@@ -89,36 +103,44 @@ def parse():
     ap.add_argument('--conv-impls', default=None,
                     help='comma list restricting the tuner, e.g. miopen,direct (no Winograd forms)')
     ap.add_argument('--no-tune', action='store_true', help='keep MIOpen + epilogue pass for every convolution')
-    ap.add_argument('--cpu-slices', type=int, default=96, help='slices of the same workload for the CPU baseline')
+    ap.add_argument('--cpu-slices', type=int, default=96, help='stack mode: slices of the workload for the CPU baseline')
+    ap.add_argument('--cpu-size', type=int, default=192,
+                    help='orthoplane mode: side of the corner sub-volume the CPU baseline (and the ids / PQ check) runs on')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-forward-check', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='run the passes strictly one after the other')
-    ap.add_argument('--mode', default='stack', choices=['stack', 'orthoplane'],
-                    help='stack = BASELINE configs[1] (xy only); orthoplane = configs[2] (xy/xz/yz + consensus, '
-                         'cubic volume of side --size, single GPU)')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 3 if args.mode == 'orthoplane' else 10
+    if args.size is None:
+        args.size = 1024 if args.mode == 'orthoplane' else 512
+    return args
 
 
-def build_inputs(D, S, device, seed_offset=0, things=1):
-    from empanada_amd import synthetic as SY
-    shape = (D, S, S)
-    from empanada_amd.data import DeviceVolume
-    vol = DeviceVolume(SY.em_volume(shape, seed=1234 + seed_offset), NORM['mean'], NORM['std'], 16, device)
-    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321 + seed_offset, n_classes=things)
-    heads = {'sem': [], 'ctr_hmp': [], 'offsets': []}
-    for s in range(0, D, 64):                    # chunked to bound the generator's temporaries
-        h = SY.planted_heads(lab, cls, 'xy', device=device, slices=slice(s, min(D, s + 64)), seed=99 + s,
-                             n_classes=things)
-        for k in heads:
-            heads[k].append(h[k])
-    heads = {k: torch.cat(v, dim=0).contiguous() for k, v in heads.items()}
-    return vol, heads, int(cls.shape[0] - 1)
+def maybe_spawn(args):
+    """`--gpus N` outside a torch.distributed launch: start the N ranks as a child job and relay its result.  This
+    process has not touched the GPU (and never will): it only waits."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
-# --model name -> label in config.workload (the FLOP count below is only known for the headline model)
-MODELS = {'pdl_r50': 'PanopticDeepLab/ResNet-50', 'bifpn_r50': 'PanopticBiFPN/ResNet-50',
-          'bifpn_regnety': 'PanopticBiFPN/RegNetY-6.4GF'}
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+_T0 = time.perf_counter()
+
+
+# ----------------------------------------------------------------------------------------------- model
 def build_model(name):
     from empanada_amd.models import PanopticBiFPN, PanopticDeepLab, synthesize_weights
     nc = 1 if len(LABELS) == 1 else len(LABELS) + 1              # binary head, or background + T classes
@@ -126,18 +148,18 @@ def build_model(name):
         model = PanopticDeepLab(encoder='resnet50', num_classes=nc)
     else:
         model = PanopticBiFPN(encoder={'bifpn_r50': 'resnet50', 'bifpn_regnety': 'regnety_6p4gf'}[name], num_classes=nc)
-    return synthesize_weights(model)
+    model = synthesize_weights(model)
+    with torch.no_grad():                     # O(1) logits like a trained model (synthetic He weights are hot)
+        for head in (model.semantic_head, model.ins_center, model.ins_xy):
+            head.head[1].weight.mul_(1e-3)
+    return model
 
 
 class Pipeline:
     def __init__(self, args, device):
         from empanada_amd.models import prepare_for_inference
         self.dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[args.dtype]
-        model = build_model(args.model)
-        with torch.no_grad():                     # O(1) logits like a trained model (synthetic He weights are hot)
-            for head in (model.semantic_head, model.ins_center, model.ins_xy):
-                head.head[1].weight.mul_(1e-3)
-        self.model = prepare_for_inference(model, device, self.dtype)
+        self.model = prepare_for_inference(build_model(args.model), device, self.dtype)
         self.device = device
         self.batch = args.batch
         self.tune_batch = args.tune_batch
@@ -145,6 +167,7 @@ class Pipeline:
         self.tuned = {}
         self.conv_impls = args.conv_impls.split(',') if args.conv_impls else None
         self.post_stream = torch.cuda.Stream(device=device)
+        self.dense_profile_left = 0               # forward() calls whose dense-path ABI calls are still event-timed
 
     def slices_per_call(self, h, w):
         return max(1, self.batch * 512 * 512 // max(h * w, 1))
@@ -183,8 +206,14 @@ class Pipeline:
     @torch.no_grad()
     def forward(self, dv, axis='xy', lo=0, hi=None):
         """slices [lo, hi) of one plane of the resident uint8 volume (empanada_amd.data.DeviceVolume: strided
-        gather + normalise + pad in one HIP pass) -> resident sem probabilities (n,1,h,w) fp32 + a checksum of all
-        heads"""
+        gather + normalise + pad in one HIP pass) -> resident sem probabilities (n,C,h,w) fp32 + a checksum of all
+        heads (fp64, device)"""
+        from empanada_amd import _hip
+        if self.dense_profile_left > 0:
+            self.dense_profile_left -= 1
+            _hip.PROFILE_SKIP.difference_update(DENSE_KERNELS)
+        else:
+            _hip.PROFILE_SKIP.update(DENSE_KERNELS)
         hi = dv.n_slices(axis) if hi is None else hi
         h, w = dv.plane_shape(axis)
         nc = 1 if len(LABELS) == 1 else len(LABELS) + 1
@@ -200,119 +229,238 @@ class Pipeline:
         return prob, chk + prob.sum(dtype=torch.float64)
 
     def postprocess(self, heads, out_host):
-        """probabilities -> labelled slab in pinned host memory.  Same code path for 1 and N ranks
+        """stack mode: probabilities -> labelled slab in pinned host memory.  Same code path for 1 and N ranks
         (empanada_amd/inference/sharded.py); with one rank the collectives are no-ops."""
         from empanada_amd.inference import sharded
-        t0 = time.perf_counter()
         pan = sharded.sharded_panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'],
                                              coarse_boundaries=False, **ENGINE)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
         vol = sharded.sharded_stack_volume(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'],
                                            min_size=FILTERS['min_size'], min_span=FILTERS['min_span'], **MATCH)
         out_host.copy_(vol.view(torch.int32), non_blocking=True)
-        t2 = time.perf_counter()
-        self.timers.setdefault('stages', []).append(
-            {'panoptic_stack_incl_wait_for_forward': t1 - t0, 'runs_chain_fill_launch': t2 - t1})
         return vol
 
 
-def build_inputs_ortho(S, device, rank=0, world=1):
-    """cubic volume; every rank holds the EM slices and planted heads of its own contiguous block per plane"""
+@torch.no_grad()
+def forward_check(args, pipe, dv, axes=('xy', 'yz')):
+    """After the timed region: the GPU forward (tuned hand-written kernels, the path that was timed) against a torch-CPU
+    forward of the same synthesised weights on one slice per listed plane; tolerance of the D1 row,
+    1e-4 * max(1, |ref|_inf) + 1e-4 per head (tests/test_pipeline_gpu.py uses the same bound)."""
+    cpu_model = build_model(args.model).eval()
+    worst, ok, detail = 0.0, True, {}
+    for axis in axes:
+        z = dv.n_slices(axis) // 2
+        x = dv.batch(axis, z, z + 1)
+        got = pipe.model(x.contiguous(memory_format=torch.channels_last))
+        ref = cpu_model(x.cpu())
+        for k in ('sem_logits', 'ctr_hmp', 'offsets'):
+            r = ref[k].float()
+            g = got[k].float().cpu()
+            err = float((g - r).abs().max())
+            tol = 1e-4 * max(1.0, float(r.abs().max())) + 1e-4
+            detail[f'{axis}:{k}'] = [round(err, 8), round(tol, 8)]
+            ok = ok and err <= tol
+            worst = max(worst, err / tol)
+    return {'ok': bool(ok), 'worst_err_over_tol': round(worst, 4), 'slices': [f'{a}[{dv.n_slices(a) // 2}]' for a in axes],
+            'tolerance': '1e-4*max(1,|ref|inf)+1e-4 per head', 'max_abs_err_and_tol': detail}
+
+
+# ----------------------------------------------------------------------------------------------- inputs
+def build_inputs(D, S, device, seed_offset=0, things=1):
+    """stack mode (and tests/test_full_size_gpu.py): (DeviceVolume, planted heads of the xy plane, #objects)"""
     from empanada_amd import synthetic as SY
+    from empanada_amd.data import DeviceVolume
+    shape = (D, S, S)
+    vol = DeviceVolume(SY.em_volume(shape, seed=1234 + seed_offset), NORM['mean'], NORM['std'], 16, device)
+    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321 + seed_offset, n_classes=things)
+    lab_dev = torch.from_numpy(lab.view(np.int16)).to(device)
+    heads = {'sem': [], 'ctr_hmp': [], 'offsets': []}
+    for s in range(0, D, 64):                    # chunked to bound the generator's temporaries
+        h = SY.planted_heads(lab_dev, cls, 'xy', device=device, slices=slice(s, min(D, s + 64)), seed=99 + s,
+                             n_classes=things)
+        for k in heads:
+            heads[k].append(h[k])
+    heads = {k: torch.cat(v, dim=0).contiguous() for k, v in heads.items()}
+    return vol, heads, int(cls.shape[0] - 1)
+
+
+def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None):
+    """cubic volume shared by all ranks; every rank holds the whole uint8 EM volume (1 GiB at 1024^3; each plane is a
+    strided view of it) and the planted heads of its own contiguous block of slices per plane"""
+    from empanada_amd import synthetic as SY
+    from empanada_amd.data import DeviceVolume
     from empanada_amd.inference.sharded import shard_bounds
     shape = (S, S, S)
     b = shard_bounds(S, world)
     lo, hi = int(b[rank]), int(b[rank + 1])
-    from empanada_amd.data import DeviceVolume
+    box = {}
+    t = threading.Thread(target=lambda: box.update(lab=SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321)))
+    t.start()                                      # numpy on the host, while the EM volume is drawn and uploaded
     dv = DeviceVolume(SY.em_volume(shape, seed=1234), NORM['mean'], NORM['std'], 16, device)
-    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321)
+    t.join()
+    lab, cls = box['lab']
+    if labels_out is not None:
+        labels_out.update(lab=lab, cls=cls)
+    lab_dev = torch.from_numpy(lab.view(np.int16)).to(device)
     heads, stacks = {}, {}
-    for axis, ax in (('xy', 0), ('xz', 1), ('yz', 2)):
+    chunk = max(1, 64 * 512 * 512 // (S * S))
+    for axis in ('xy', 'xz', 'yz'):
         stacks[axis] = (dv, axis, lo, hi)          # the rank's block of the plane: a strided view of the volume
         parts = {'sem': [], 'ctr_hmp': [], 'offsets': []}
-        for s in range(lo, hi, 64):
-            h = SY.planted_heads(lab, cls, axis, device=device, slices=slice(s, min(hi, s + 64)), seed=99 + s)
+        for s in range(lo, hi, chunk):
+            h = SY.planted_heads(lab_dev, cls, axis, device=device, slices=slice(s, min(hi, s + chunk)), seed=99 + s)
             for k in parts:
                 parts[k].append(h[k])
         heads[axis] = {k: torch.cat(v, dim=0).contiguous() for k, v in parts.items()}
+    del lab_dev
     return stacks, heads, int(cls.shape[0] - 1), lo
 
 
-def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages, first=None, prefetch_next=False):
-    """One pass of BASELINE configs[2]: three slice-sharded stacks (xy, xz, yz) -> trackers stitched on rank 0 ->
-    filters -> instance consensus -> filters -> labelled volume in pinned host memory
-    (scripts/pdl_inference3d.py:110-233 in orthoplane mode).
-    Consecutive passes are software-pipelined like the stack mode: with prefetch_next the xy forward of the NEXT pass
-    is queued as soon as this pass's yz tables are on the host, so the tail (yz tracking, consensus, fill, D2H; post
-    stream + host) runs under it; the caller hands the returned (checksum, event) back as `first`."""
+# ----------------------------------------------------------------------------------------------- orthoplane
+def postprocess_planes(heads, shape3d, slice0, host_out, stages, between=None):
+    """The part of a pass that follows the forwards, for all three planes (heads[axis] = the rank's block of head
+    tensors): per plane pixels -> tables -> chain -> trackers, then filters -> consensus -> filters -> fill -> pinned
+    host memory on the rank that holds the result.  `between(i)` is called once plane i's device tables are on the host
+    (the driver queues the next forward there).  Returns (#consensus instances or 0, volume tensor or None)."""
     from empanada_amd.inference import sharded
     trackers = {}
-    chk = 0
-    # Two HIP streams.  The forward of plane p+1 is queued (default stream) as soon as the device tables of plane p
-    # are on the host; the host half of plane p (label-propagation chain, tracker assembly) and its device work
-    # (D2H copies, yz scatter) run on the post-processing stream meanwhile, so neither side waits for the other.
-    # (Queuing all three forwards up front does not work: ~14k launches exceed the HIP queue and the host blocks.)
+    planes = ('xy', 'xz', 'yz')
+    for i, axis in enumerate(planes):
+        t0 = time.perf_counter()
+        h = heads[axis]
+        pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False, **ENGINE)
+        table, host = sharded.sharded_tables(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'])
+        t1 = time.perf_counter()
+        if between is not None:
+            between(i)
+        t2 = time.perf_counter()
+        trackers[axis] = sharded.finish_plane(table, host, pan.shape[0], axis, shape3d, slice0, LABELS,
+                                              ENGINE['thing_list'], ENGINE['label_divisor'], **MATCH)
+        stages[f'{axis}_wait_forward_pixels_tables'] = stages.get(f'{axis}_wait_forward_pixels_tables', 0) + t1 - t0
+        stages[f'{axis}_enqueue_next_forward'] = stages.get(f'{axis}_enqueue_next_forward', 0) + t2 - t1
+        stages[f'{axis}_tracking'] = stages.get(f'{axis}_tracking', 0) + time.perf_counter() - t2
+    n_found, vol = 0, None
+    if trackers['xy'] is not None:                   # rank 0 holds the stitched trackers
+        t0 = time.perf_counter()
+        cons, vols = sharded.consensus_volume(trackers, shape3d, LABELS, ENGINE['thing_list'],
+                                              CONSENSUS['pixel_vote_thr'], CONSENSUS['cluster_iou_thr'],
+                                              CONSENSUS['bypass'], FILTERS['min_size'], FILTERS['min_span'])
+        t1 = time.perf_counter()
+        vol = vols[1]
+        if host_out is not None:
+            host_out.copy_(vol.view(torch.int32), non_blocking=True)
+            torch.cuda.current_stream().synchronize()      # the post stream only: a prefetched forward keeps running
+        stages['consensus_and_fill'] = stages.get('consensus_and_fill', 0) + t1 - t0
+        stages['to_host'] = stages.get('to_host', 0) + time.perf_counter() - t1
+        n_found = len(cons[1].instances)
+    return n_found, vol
+
+
+def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages, first=None, prefetch_next=False):
+    """One pass.  Two HIP streams: the forward of plane p+1 is queued (default stream) as soon as the device tables of
+    plane p are on the host; the host half of plane p and its device work run on the post-processing stream meanwhile.
+    With prefetch_next the xy forward of the NEXT pass is queued the same way behind the yz tables, so that the tail
+    (yz tracking, consensus, fill, D2H) runs under it; the caller hands the returned (checksum, event) back as `first`."""
     post = pipe.post_stream
     planes = ('xy', 'xz', 'yz')
+    state = {'chk': 0, 'next': None}
     if first is None:
-        prob, c = pipe.forward(*stacks['xy'])
+        _, c = pipe.forward(*stacks['xy'])
         ev = torch.cuda.Event()
         ev.record()
     else:
         c, ev = first
-    chk = chk + c
-    nxt = None
-    with torch.cuda.stream(post):
-        for i, axis in enumerate(planes):
-            t0 = time.perf_counter()
-            post.wait_event(ev)
-            h = heads[axis]
-            pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False,
-                                                 **ENGINE)
-            table, host = sharded.sharded_tables(pan, [1], ENGINE['thing_list'], ENGINE['label_divisor'])
-            t1 = time.perf_counter()
+    state['chk'] = c
+    state['ev'] = ev
+
+    def between(i):
+        with torch.cuda.stream(torch.cuda.default_stream()):
             if i + 1 < len(planes):
-                with torch.cuda.stream(torch.cuda.default_stream()):
-                    prob, c = pipe.forward(*stacks[planes[i + 1]])
-                    chk = chk + c
-                    ev = torch.cuda.Event()
-                    ev.record()
+                _, c = pipe.forward(*stacks[planes[i + 1]])
+                state['chk'] = state['chk'] + c
+                e = torch.cuda.Event()
+                e.record()
+                state['ev'] = e
             elif prefetch_next:
-                with torch.cuda.stream(torch.cuda.default_stream()):
-                    prob, c2 = pipe.forward(*stacks['xy'])
-                    ev2 = torch.cuda.Event()
-                    ev2.record()
-                    nxt = (c2, ev2)
-            t2 = time.perf_counter()
-            trackers[axis] = sharded.finish_plane(table, host, pan.shape[0], axis, shape3d, slice0, [1],
-                                                  ENGINE['thing_list'], ENGINE['label_divisor'], **MATCH)
-            stages[f'{axis}_wait_forward_pixels_tables'] = stages.get(f'{axis}_wait_forward_pixels_tables', 0) + t1 - t0
-            stages[f'{axis}_enqueue_next_forward'] = stages.get(f'{axis}_enqueue_next_forward', 0) + t2 - t1
-            stages[f'{axis}_tracking'] = stages.get(f'{axis}_tracking', 0) + time.perf_counter() - t2
-        n_found = _orthoplane_finish(trackers, shape3d, host_out, stages)
+                _, c2 = pipe.forward(*stacks['xy'])
+                e2 = torch.cuda.Event()
+                e2.record()
+                state['next'] = (c2, e2)
+
+    class _Heads(dict):                              # heads[axis] access = "plane `axis` starts": wait for its forward
+        def __getitem__(self, axis):
+            post.wait_event(state['ev'])
+            return dict.__getitem__(self, axis)
+
+    with torch.cuda.stream(post):
+        n_found, _ = postprocess_planes(_Heads(heads), shape3d, slice0, host_out, stages, between)
     torch.cuda.current_stream().wait_stream(post)
-    return chk, n_found, nxt
+    return state['chk'], n_found, state['next']
 
 
-def _orthoplane_finish(trackers, shape3d, host_out, stages):
-    from empanada_amd.inference import sharded
-    n_found = 0
-    if trackers['xy'] is not None:                   # rank 0 holds the stitched trackers
-        t0 = time.perf_counter()
-        cons, vols = sharded.consensus_volume(trackers, shape3d, [1], ENGINE['thing_list'], 2, 0.75, False,
-                                              FILTERS['min_size'], FILTERS['min_span'])
-        t1 = time.perf_counter()
-        host_out.copy_(vols[1].view(torch.int32), non_blocking=True)
-        torch.cuda.current_stream().synchronize()          # the post stream only: a prefetched forward keeps running
-        stages['consensus_and_fill'] = stages.get('consensus_and_fill', 0) + t1 - t0
-        stages['to_host'] = stages.get('to_host', 0) + time.perf_counter() - t1
-        n_found = len(cons[1].instances)
-    return n_found
+def cpu_baseline_ortho(args, n, cores):
+    """CPU leg of the orthoplane workload on a bounded sample: the n^3 corner sub-volume of the same synthetic volume
+    recipe (EM voxels, planted objects clipped to the sub-volume, heads derived from them for all three planes).
+    torch-CPU forward over the 3n slices + the oracle chain (CPU restatement of the reference) for every plane +
+    oracle consensus + fill; then the HIP path on exactly the same heads -> ids_identical / PQ on the consensus volume.
+    kind = 'port'."""
+    from empanada_amd import synthetic as SY
+    from empanada_amd.evaluation import volume_pq
+    from oracle import consensus as OC
+    from oracle import postprocess as OP
+    from oracle import rle_ops as OR
+    from oracle import rle_seg as OS
+    shape = (n, n, n)
+    torch.set_num_threads(cores)
+    em = SY.em_volume(shape, seed=1234)
+    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321)
+    heads = {a: SY.planted_heads(lab, cls, a, seed=99) for a in ('xy', 'xz', 'yz')}
+    model = build_model(args.model).eval()
+    div, things = ENGINE['label_divisor'], ENGINE['thing_list']
+    t0 = time.perf_counter()
+    t_conv = 0.0
+    trackers = OS.create_axis_trackers(['xy', 'xz', 'yz'], LABELS, div, shape)
+    for ax, axis in enumerate(('xy', 'xz', 'yz')):
+        tc = time.perf_counter()
+        x = torch.from_numpy(np.ascontiguousarray(np.moveaxis(em, ax, 0))).float().unsqueeze(1)
+        x = (x - 255 * NORM['mean']) / (255 * NORM['std'])
+        with torch.no_grad():
+            for i in range(n):
+                out = model(x[i:i + 1])
+                _ = torch.sigmoid(out['sem_logits'])
+        t_conv += time.perf_counter() - tc
+        sem, ctr, off = (heads[axis][k].numpy() for k in ('sem', 'ctr_hmp', 'offsets'))
+        pans = OP.engine3d_stack([sem[t:t + 1] for t in range(n)], [ctr[t:t + 1] for t in range(n)],
+                                 [off[t:t + 1] for t in range(n)], coarse_boundaries=False, render=True, **ENGINE)
+        pans = [p.squeeze() for p in pans]
+        matchers = OS.create_matchers(things, div, MATCH['merge_iou_thr'], MATCH['merge_ioa_thr'])
+        stack = OS.forward_matching(pans, matchers, LABELS, div, things)
+        for idx, rs in OS.backward_matching(stack, matchers, len(pans)):
+            OS.update_trackers(rs, idx, trackers[axis])
+        OS.finish_tracking(trackers[axis])
+        for tr in trackers[axis]:
+            OS.remove_small_objects(tr, FILTERS['min_size'])
+            OS.remove_pancakes(tr, FILTERS['min_span'])
+    cts = [t for axis in ('xy', 'xz', 'yz') for t in trackers[axis] if t.class_id == 1]
+    con = OC.create_instance_consensus(cts, CONSENSUS['pixel_vote_thr'], CONSENSUS['cluster_iou_thr'], CONSENSUS['bypass'])
+    OS.remove_small_objects(con, FILTERS['min_size'])
+    OS.remove_pancakes(con, FILTERS['min_span'])
+    ref = OR.numpy_fill_instances(np.zeros(shape, np.uint32), con.instances)
+    dt = time.perf_counter() - t0
+    # the HIP path on exactly the same heads
+    dev_heads = {a: {k: v.cuda().contiguous() for k, v in heads[a].items()} for a in heads}
+    _, vol = postprocess_planes(dev_heads, shape, 0, None, {})
+    got = vol.view(torch.int32).cpu().numpy().astype(np.uint32)
+    pq, n_gt, n_pred, n_match = volume_pq(ref, got)
+    return {'value': round(float(n) ** 3 / dt / 1e6, 4), 'unit': 'Mvox/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n}^3 corner sub-volume of the same recipe: all three planes ({3 * n} slices of {n}x{n}) + '
+                      f'consensus + fill; conv {t_conv:.1f}s of {dt:.1f}s',
+            'objects': int(len(con.instances)), 'pq_vs_cpu_ref': round(pq, 6),
+            'ids_identical': bool(np.array_equal(ref, got)), 'instances_cpu_gpu_matched': [n_gt, n_pred, n_match]}
 
 
 def main_orthoplane(args, device, rank, world):
     import torch.distributed as dist
+    from empanada_amd import _hip
     S = args.size
     log(f'orthoplane: building inputs {S}^3 (rank {rank}/{world})')
     stacks, heads, n_obj, slice0 = build_inputs_ortho(S, device, rank, world)
@@ -333,37 +481,113 @@ def main_orthoplane(args, device, rank, world):
         orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, {})
         log(f'warmup {i} done')
     barrier()
-    stages = {}
+    _hip.PROFILE = {}
+    pipe.dense_profile_left = 3                      # the dense-path calls of the first pass's three forwards are timed
+    stages, chks = {}, []
     t0 = time.perf_counter()
     first = None
     for k in range(args.steps):
         chk, n_found, first = orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages, first,
                                               prefetch_next=(k + 1 < args.steps) and not args.no_pipeline)
+        chks.append(chk)
     barrier()
     dt = time.perf_counter() - t0
+    log(f'timed {args.steps} steps in {dt:.2f}s')
+    prof, _hip.PROFILE = _hip.PROFILE, None
+    _hip.PROFILE_SKIP.clear()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
         return
+    chks = [float(c) for c in chks]
+    vox_launch = float(S) ** 3 / world               # voxels one post-processing launch covers (a rank's block of a plane)
+    thing_frac = float((heads['xy']['sem'] >= ENGINE['confidence_thr']).float().mean().item())
+    roof, per_call, per_pass = roofline_block(prof, vox_launch, thing_frac, args.steps, dense_passes=1)
+    fwd_ms_pass = sum(v for k, v in per_pass.items() if k in DENSE_KERNELS)
     res = {
-        'metric': 'Mvox/s end-to-end 3D panoptic inference (incl. consensus); PQ vs CPU ref',
+        'metric': METRIC,
         'value': round(float(S) ** 3 * args.steps / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f32' if args.dtype == 'fp32' else args.dtype, 'data': 'synthetic',
-        'config': {'workload': f'orthoplane (xy/xz/yz) inference + instance consensus, {S}^3 uint8 volume, '
-                               f'{MODELS[args.model]} C=1 forward on every slice of every plane + HIP '
-                               f'post-processing on planted heads, {n_obj} planted objects, slices sharded over '
+        'config': {'workload': f'orthoplane (xy/xz/yz) inference + instance consensus, {S}^3 uint8 volume '
+                               f'(BASELINE configs[{3 if S >= 1024 else 2}] volume), {MODELS[args.model]} C=1 fp32 '
+                               f'forward on every slice of every plane + HIP post-processing on planted heads '
+                               f'(ks=7, full-res heads), {n_obj} planted objects, slices of every plane sharded over '
                                f'{world} rank(s)',
-                   'mode': 'orthoplane', 'objects_found': int(n_found)},
-        'stages_s_per_step': {k: round(v / args.steps, 4) for k, v in stages.items()},
+                   'mode': 'orthoplane', 'size': S, 'objects_found': int(n_found),
+                   'batch': pipe.slices_per_call(S, S)},
+        'breakdown': {'stages_s_per_step': {k: round(v / args.steps, 4) for k, v in stages.items()},
+                      'hand_written_dense_ms_per_pass_rank0': round(fwd_ms_pass, 1),
+                      'forward_TFLOPs_if_gpu_bound': round(3 * FLOPS_PER_VOXEL_PDL_R50 * float(S) ** 3 / world
+                                                           / (dt / args.steps) / 1e12, 2)
+                      if args.model == 'pdl_r50' else None,
+                      'pipelined': not args.no_pipeline, 'conv_impls': pipe.tuned},
+        'forward_checksum': chks[-1], 'forward_checksum_stable': bool(all(c == chks[0] for c in chks)),
+        'hip_calls_ms': per_call, 'hip_ms_per_pass': per_pass, 'roofline': roof,
     }
+    if not args.no_forward_check:
+        log('forward check against the CPU')
+        res['forward_check'] = forward_check(args, pipe, stacks['xy'][0])
+    if not args.no_cpu_baseline and world == 1 and args.cpu_size > 0:
+        log('cpu baseline')
+        del heads
+        torch.cuda.empty_cache()
+        res['cpu_baseline'] = cpu_baseline_ortho(args, min(args.cpu_size, S), min(16, os.cpu_count() or 1))
+    else:
+        res['cpu_baseline'] = None
     print(json.dumps(res), flush=True)
 
 
-def cpu_baseline(args, vol_u8, heads, n_slices):
+# ----------------------------------------------------------------------------------------------- accounting
+def roofline_block(prof, vox_launch, thing_frac, steps, dense_passes):
+    """HIP-event brackets of every ABI call inside the timed region (events on the stream the kernels are launched
+    on, empanada_amd/_hip.py:call) -> per-call statistics and the `roofline` object of the dominant hand-written
+    kernel.  The per-voxel kernels process a whole block of slices per launch (ALG_BYTES x vox_launch); the dense-path
+    kernels report their algorithmic bytes / flops per call (shapes vary by layer) and are sampled during
+    `dense_passes` of the timed passes so that event packets do not perturb the rest."""
+    stat = {}
+    for name, evs in prof.items():
+        ms = [e[0].elapsed_time(e[1]) for e in evs]
+        by = [e[2] if e[2] is not None else (ALG_BYTES[name](thing_frac) * vox_launch if name in ALG_BYTES else None)
+              for e in evs]
+        fl = [e[3] for e in evs]
+        passes = dense_passes if name in DENSE_KERNELS else steps
+        stat[name] = {'calls_per_pass': len(ms) / passes, 'ms_per_pass': float(np.sum(ms)) / passes,
+                      'avg_ms': float(np.mean(ms)), 'n': len(ms),
+                      'bytes': float(np.sum(by)) if all(b is not None for b in by) else None,
+                      'flops': float(np.sum(fl)) if all(f is not None for f in fl) else None}
+    per_call = {k: round(v['avg_ms'], 4) for k, v in sorted(stat.items(), key=lambda kv: -kv[1]['avg_ms'])}
+    per_pass = {k: round(v['ms_per_pass'], 3) for k, v in sorted(stat.items(), key=lambda kv: -kv[1]['ms_per_pass'])}
+    gbps = {k: round(v['bytes'] / (v['avg_ms'] * v['n'] * 1e-3) / 1e9, 1) for k, v in stat.items()
+            if v['bytes'] is not None}
+    tflops = {k: round(v['flops'] / (v['avg_ms'] * v['n'] * 1e-3) / 1e12, 1) for k, v in stat.items()
+              if v['flops'] is not None}
+    # dominant hand-written kernel = most GPU time per pass among the calls with a byte / flop model
+    dom = max((k for k in stat if stat[k]['bytes'] is not None), key=lambda k: stat[k]['ms_per_pass'])
+    n_dom = stat[dom]['n']
+    alg = stat[dom]['bytes'] / n_dom                                  # algorithmic bytes per launch (mean)
+    traffic = round(PMC_TRAFFIC_RATIO[dom] * alg) if dom in PMC_TRAFFIC_RATIO else None
+    if dom in MFMA_KERNELS:
+        roof = {'bound': 'mfma', 'kernel': dom, 'achieved': tflops[dom], 'peak': MFMA_F32_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(tflops[dom] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+                'alg_flops_per_launch': round(stat[dom]['flops'] / n_dom)}
+    else:
+        roof = {'bound': 'hbm', 'kernel': dom, 'achieved': gbps[dom], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(gbps[dom] / HBM_PEAK_GBS, 4), 'traffic': traffic}
+    roof.update({'traffic_source': PMC_SOURCE if traffic is not None else None,
+                 'alg_bytes_per_launch': round(alg), 'avg_launch_ms': round(stat[dom]['avg_ms'], 4),
+                 'launches_per_pass': stat[dom]['calls_per_pass'],
+                 'ms_per_pass': round(stat[dom]['ms_per_pass'], 3), 'thing_fraction': round(thing_frac, 4),
+                 'alg_bytes_per_voxel': {k: round(f(thing_frac), 3) for k, f in ALG_BYTES.items()},
+                 'all_kernels_GBps': gbps, 'mfma_kernels_TFLOPs': tflops})
+    return roof, per_call, per_pass
+
+
+# ----------------------------------------------------------------------------------------------- stack mode
+def cpu_baseline_stack(args, vol_u8, heads, n_slices):
     """The oracle chain (CPU restatement of the reference) + torch-CPU forward on a bounded sample of the
     same workload: the first n_slices slices.  kind = 'port'."""
     from oracle import postprocess as OP
@@ -417,40 +641,10 @@ def cpu_baseline(args, vol_u8, heads, n_slices):
             'instances_cpu_gpu_matched': [n_gt, n_pred, n_match]}
 
 
-def log(msg):
-    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
-
-
-_T0 = time.perf_counter()
-
-
-def main():
-    args = parse()
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+def main_stack(args, device, rank, world):
     import torch.distributed as dist
-    backend = os.environ.get('EMP_BENCH_BACKEND', 'nccl')     # 'gloo': rehearse N ranks on fewer GPUs (not a measurement)
-    if backend == 'gloo':
-        local = local % max(torch.cuda.device_count(), 1)
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend)
-    device = torch.device('cuda', local)
-    torch.cuda.set_device(device)
     from empanada_amd import _hip
-    _hip.load()
-    torch.backends.cudnn.benchmark = True
-
-    if args.things > 1:
-        assert args.mode == 'stack', '--things > 1 is implemented for the stack mode'
-        LABELS[:] = list(range(1, args.things + 1))
-        ENGINE['thing_list'] = list(LABELS)
-    if args.mode == 'orthoplane':
-        main_orthoplane(args, device, rank, world)
-        if world > 1:
-            dist.destroy_process_group()
-        return
+    from empanada_amd.inference import sharded
     D, S = args.depth, args.size
     log(f'building inputs {D}x{S}x{S}')
     vol, heads, n_obj = build_inputs(D, S, device, seed_offset=rank, things=args.things)
@@ -459,7 +653,6 @@ def main():
     if not args.no_tune:
         pipe.tune(S, args.save_tune, args.load_tune)
     host_out = torch.empty((D, S, S), dtype=torch.int32).pin_memory()
-    shape3d = (D, S, S)
 
     def barrier():
         torch.cuda.synchronize()
@@ -470,20 +663,20 @@ def main():
     for i in range(args.warmup):
         t_w = time.perf_counter()
         prob, chk = pipe.forward(vol)
-        torch.cuda.synchronize()
-        log(f'warmup {i}: forward {time.perf_counter() - t_w:.2f}s')
         out = pipe.postprocess(heads, host_out)
         torch.cuda.synchronize()
         log(f'warmup {i}: total {time.perf_counter() - t_w:.2f}s')
     barrier()
     _hip.PROFILE = {}
+    pipe.dense_profile_left = 1 if not args.no_pipeline else args.steps
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
-    from empanada_amd.inference import sharded
+    chks = []
     t0 = time.perf_counter()
     if args.no_pipeline:
         for k in range(args.steps):
             ev[3 * k].record()
             prob, chk = pipe.forward(vol)
+            chks.append(chk)
             ev[3 * k + 1].record()
             out = pipe.postprocess(heads, host_out)
             ev[3 * k + 2].record()
@@ -516,9 +709,9 @@ def main():
             if k < args.steps:
                 ev[3 * k].record()
                 prob, chk = pipe.forward(vol)                      # asynchronous: only enqueues
+                chks.append(chk)
                 ev[3 * k + 1].record()
                 fwd_done[k].record()
-                _hip.PROFILE_SKIP.update(DENSE_KERNELS)            # the dense-path calls are sampled in pass 0
             if k > 0:
                 out = downstream(k - 1)
         torch.cuda.current_stream().wait_stream(post)
@@ -531,85 +724,74 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if rank != 0:
+        return
+    chks = [float(c) for c in chks]
+    vox_total = float(D) * S * S * world * args.steps
+    fwd_ms = np.mean([ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(args.steps)])
+    post_ms = np.mean([ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(args.steps)])
+    if len(LABELS) == 1:
+        thing_frac = float((heads['sem'] >= ENGINE['confidence_thr']).float().mean().item())
+    else:
+        thing_frac = float((heads['sem'].argmax(dim=1) > 0).float().mean().item())
+    roof, per_call, per_pass = roofline_block(prof, float(D) * S * S, thing_frac, args.steps,
+                                              dense_passes=1 if not args.no_pipeline else args.steps)
+    flops = FLOPS_PER_VOXEL_PDL_R50 * D * S * S
+    res = {
+        'metric': 'Mvox/s end-to-end 3D panoptic inference, xy stack only (no consensus); PQ vs CPU ref',
+        'value': round(vox_total / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else args.dtype,
+        'data': 'synthetic',
+        'config': {'workload': f'stack (xy) inference, {D * world}x{S}x{S} uint8 volume (an independent {D}-slice '
+                               f'volume per rank), {MODELS[args.model]} '
+                               f'C={1 if len(LABELS) == 1 else len(LABELS) + 1} fp-forward on every slice + HIP '
+                               f'post-processing on planted heads (ks=7, full-res heads), {n_obj} planted objects per rank',
+                   'mode': 'stack', 'slices_per_rank': D, 'batch': pipe.slices_per_call(S, S),
+                   'objects_found': int(len(np.unique(host_out.numpy())) - 1)},
+        'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'forward_end_to_slab_on_host': round(float(post_ms), 2),
+                         'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2)
+                         if args.model == 'pdl_r50' and len(LABELS) == 1 else None,
+                         'pipelined': not args.no_pipeline, 'conv_impls': pipe.tuned,
+                         'host_chain_s': round(float(np.mean(pipe.timers.get('chain_s', [0]))), 4)},
+        'forward_checksum': chks[-1], 'forward_checksum_stable': bool(all(c == chks[0] for c in chks)),
+        'hip_calls_ms': per_call, 'hip_ms_per_pass': per_pass, 'roofline': roof,
+    }
+    if not args.no_forward_check:
+        res['forward_check'] = forward_check(args, pipe, vol, axes=('xy',))
+    if not args.no_cpu_baseline and world == 1 and args.cpu_slices > 0:
+        log('cpu baseline')
+        res['cpu_baseline'] = cpu_baseline_stack(args, vol.vol, heads, args.cpu_slices)
+    else:
+        res['cpu_baseline'] = None
+    print(json.dumps(res), flush=True)
 
-    if rank == 0:
-        vox_total = float(D) * S * S * world * args.steps
-        ms_step = dt / args.steps * 1e3
-        fwd_ms = np.mean([ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(args.steps)])
-        post_ms = np.mean([ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(args.steps)])
-        if len(LABELS) == 1:
-            thing_frac = float((heads['sem'] >= ENGINE['confidence_thr']).float().mean().item())
-        else:
-            thing_frac = float((heads['sem'].argmax(dim=1) > 0).float().mean().item())
-        vox = float(D) * S * S
-        # per ABI call: launches, total ms and algorithmic bytes inside the timed region.  The per-voxel kernels
-        # process the whole slab in one launch (ALG_BYTES x voxels); the dense-path kernels report their bytes
-        # per call (shapes vary by layer) and are sampled during the first timed pass.
-        stat = {}
-        for name, evs in prof.items():
-            ms = [e[0].elapsed_time(e[1]) for e in evs]
-            by = [e[2] if e[2] is not None else (ALG_BYTES[name](thing_frac) * vox if name in ALG_BYTES else None)
-                  for e in evs]
-            fl = [e[3] for e in evs]
-            passes = 1 if (name in DENSE_KERNELS and not args.no_pipeline) else args.steps
-            stat[name] = {'calls_per_pass': len(ms) / passes, 'ms_per_pass': float(np.sum(ms)) / passes,
-                          'avg_ms': float(np.mean(ms)),
-                          'bytes': float(np.sum(by)) if all(b is not None for b in by) else None,
-                          'flops': float(np.sum(fl)) if all(f is not None for f in fl) else None}
-        kern = {k: v['avg_ms'] for k, v in stat.items()}
-        per_call = {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}
-        per_pass = {k: round(v['ms_per_pass'], 3) for k, v in sorted(stat.items(), key=lambda kv: -kv[1]['ms_per_pass'])}
-        roofs = {k: round(v['bytes'] / (v['avg_ms'] * len(prof[k]) * 1e-3) / 1e9, 1)
-                 for k, v in stat.items() if v['bytes'] is not None}
-        tflops = {k: round(v['flops'] / (v['avg_ms'] * len(prof[k]) * 1e-3) / 1e12, 1)
-                  for k, v in stat.items() if v['flops'] is not None}
-        # dominant hand-written kernel = most GPU time per pass among the calls with a byte / flop model
-        dom = max((k for k in stat if stat[k]['bytes'] is not None), key=lambda k: stat[k]['ms_per_pass'])
-        n_dom = len(prof[dom])
-        alg = stat[dom]['bytes'] / n_dom                                  # algorithmic bytes per launch (mean)
-        if dom in PMC_TRAFFIC_BYTES_PER_VOXEL:
-            traffic = round(PMC_TRAFFIC_BYTES_PER_VOXEL[dom] * vox)
-        elif PMC_TRAFFIC_RATIO.get(dom) is not None:
-            traffic = round(PMC_TRAFFIC_RATIO[dom] * alg)
-        else:
-            traffic = None
-        if dom in MFMA_KERNELS:
-            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': tflops[dom], 'peak': MFMA_F32_PEAK_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(tflops[dom] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
-                    'alg_flops_per_launch': round(stat[dom]['flops'] / n_dom)}
-        else:
-            roof = {'bound': 'hbm', 'kernel': dom, 'achieved': roofs[dom], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(roofs[dom] / HBM_PEAK_GBS, 4), 'traffic': traffic}
-        roof.update({'alg_bytes_per_launch': round(alg), 'avg_launch_ms': round(kern[dom], 4),
-                     'launches_per_pass': stat[dom]['calls_per_pass'],
-                     'ms_per_pass': round(stat[dom]['ms_per_pass'], 3), 'thing_fraction': round(thing_frac, 4),
-                     'alg_bytes_per_voxel': {k: round(f(thing_frac), 3) for k, f in ALG_BYTES.items()},
-                     'all_kernels_GBps': roofs, 'mfma_kernels_TFLOPs': tflops})
-        flops = 414477.0 * D * S * S                                      # PDL-R50, C=1
-        res = {
-            'metric': 'Mvox/s end-to-end 3D panoptic inference (incl. consensus); PQ vs CPU ref',
-            'value': round(vox_total / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms_step, 2), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'stack (xy) inference, {D * world}x{S}x{S} uint8 volume, {MODELS[args.model]} '
-                                   f'C={1 if len(LABELS) == 1 else len(LABELS) + 1} fp-forward on every slice + HIP post-processing on planted heads '
-                                   f'(ks=7, full-res heads), {n_obj} planted objects per rank',
-                       'mode': 'stack', 'slices_per_rank': D, 'batch': pipe.slices_per_call(S, S),
-                       'objects_found': int(len(np.unique(host_out.numpy())) - 1)},
-            'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'forward_end_to_slab_on_host': round(float(post_ms), 2),
-                             'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2) if args.model == 'pdl_r50' and len(LABELS) == 1 else None,
-                             'pipelined': not args.no_pipeline, 'conv_impls': pipe.tuned,
-                             'host_chain_s': round(float(np.mean(pipe.timers.get('chain_s', [0]))), 4)},
-            'hip_calls_ms': per_call,
-            'hip_ms_per_pass': per_pass,
-            'roofline': roof,
-        }
-        if not args.no_cpu_baseline and world == 1 and args.cpu_slices > 0:
-            log('cpu baseline')
-            res['cpu_baseline'] = cpu_baseline(args, vol.vol, heads, args.cpu_slices)
-        else:
-            res['cpu_baseline'] = None
-        print(json.dumps(res), flush=True)
+
+def main():
+    args = parse()
+    maybe_spawn(args)
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus and rank == 0:
+        log(f'--gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}')
+    import torch.distributed as dist
+    backend = os.environ.get('EMP_BENCH_BACKEND', 'nccl')     # 'gloo': rehearse N ranks on fewer GPUs (not a measurement)
+    if backend == 'gloo':
+        local = local % max(torch.cuda.device_count(), 1)
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group(backend, device_id=device if backend == 'nccl' else None)
+    from empanada_amd import _hip
+    _hip.load()
+    torch.backends.cudnn.benchmark = True
+
+    if args.things > 1:
+        assert args.mode == 'stack', '--things > 1 is implemented for the stack mode'
+        LABELS[:] = list(range(1, args.things + 1))
+        ENGINE['thing_list'] = list(LABELS)
+    (main_orthoplane if args.mode == 'orthoplane' else main_stack)(args, device, rank, world)
     if world > 1:
         dist.destroy_process_group()
 
