@@ -109,6 +109,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-forward-check', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='run the passes strictly one after the other')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel of the forward from Python (no HIP graph)')
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 3 if args.mode == 'orthoplane' else 10
@@ -168,6 +169,14 @@ class Pipeline:
         self.conv_impls = args.conv_impls.split(',') if args.conv_impls else None
         self.post_stream = torch.cuda.Stream(device=device)
         self.dense_profile_left = 0               # forward() calls whose dense-path ABI calls are still event-timed
+        # One model call = ~350 kernels behind several hundred Python module calls (~45 ms of host time per call, 1.4 s
+        # per 1024-slice plane): with the host also running the chain and the consensus tables, launching is what the
+        # pass waits for.  The call is captured once per input shape in a HIP graph and replayed (one launch); the
+        # forwards whose kernels are individually event-timed for the roofline block run un-captured.
+        self.graphed = None
+        if not args.no_graph:
+            from empanada_amd.models.graphed import GraphedForward
+            self.graphed = GraphedForward(self.model, warmup=1, max_graphs=4, clone_outputs=False)
 
     def slices_per_call(self, h, w):
         return max(1, self.batch * 512 * 512 // max(h * w, 1))
@@ -209,11 +218,14 @@ class Pipeline:
         gather + normalise + pad in one HIP pass) -> resident sem probabilities (n,C,h,w) fp32 + a checksum of all
         heads (fp64, device)"""
         from empanada_amd import _hip
+        model = self.model
         if self.dense_profile_left > 0:
             self.dense_profile_left -= 1
             _hip.PROFILE_SKIP.difference_update(DENSE_KERNELS)
         else:
             _hip.PROFILE_SKIP.update(DENSE_KERNELS)
+            if self.graphed is not None and self.dtype == torch.float32:
+                model = self.graphed
         hi = dv.n_slices(axis) if hi is None else hi
         h, w = dv.plane_shape(axis)
         nc = 1 if len(LABELS) == 1 else len(LABELS) + 1
@@ -222,7 +234,7 @@ class Pipeline:
         for s, x in dv.batches(axis, self.slices_per_call(h, w), lo, hi):
             if self.dtype != torch.float32:
                 x = x.to(self.dtype)
-            out = self.model(x.contiguous(memory_format=torch.channels_last))
+            out = model(x.contiguous(memory_format=torch.channels_last))
             logits = out['sem_logits'][..., :h, :w].float()          # logits_to_prob, engines.py:22-30
             prob[s - lo:s - lo + x.shape[0]] = torch.sigmoid(logits) if nc == 1 else torch.softmax(logits, dim=1)
             chk += out['ctr_hmp'].float().sum(dtype=torch.float64) + out['offsets'].float().sum(dtype=torch.float64)
@@ -316,15 +328,15 @@ def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None):
 
 
 # ----------------------------------------------------------------------------------------------- orthoplane
-def postprocess_planes(heads, shape3d, slice0, host_out, stages, between=None):
+def postprocess_planes(heads, shape3d, host_out, stages, between=None):
     """The part of a pass that follows the forwards, for all three planes (heads[axis] = the rank's block of head
-    tensors): per plane pixels -> tables -> chain -> trackers, then filters -> consensus -> filters -> fill -> pinned
-    host memory on the rank that holds the result.  `between(i)` is called once plane i's device tables are on the host
-    (the driver queues the next forward there).  Returns (#consensus instances or 0, volume tensor or None)."""
+    tensors): per plane pixels -> tables -> chain (replicated on every rank) -> device-resident trackers, then filters
+    -> consensus -> filters -> fill of the rank's z-slab -> pinned host memory.  `between(i)` is called once plane
+    i's device tables are on the host (the driver queues the next forward there).
+    Returns (#consensus instances, the rank's slab of the labelled volume on the device, (z0, z1))."""
     from empanada_amd.inference import sharded
-    trackers = {}
-    planes = ('xy', 'xz', 'yz')
-    for i, axis in enumerate(planes):
+    planes, base = {}, 0
+    for i, axis in enumerate(('xy', 'xz', 'yz')):
         t0 = time.perf_counter()
         h = heads[axis]
         pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False, **ENGINE)
@@ -333,29 +345,27 @@ def postprocess_planes(heads, shape3d, slice0, host_out, stages, between=None):
         if between is not None:
             between(i)
         t2 = time.perf_counter()
-        trackers[axis] = sharded.finish_plane(table, host, pan.shape[0], axis, shape3d, slice0, LABELS,
-                                              ENGINE['thing_list'], ENGINE['label_divisor'], **MATCH)
+        planes[axis] = sharded.finish_plane(table, host, pan.shape[0], axis, shape3d, LABELS, ENGINE['thing_list'],
+                                            ENGINE['label_divisor'], inst_base=base, **MATCH)
+        base += planes[axis].n_inst
         stages[f'{axis}_wait_forward_pixels_tables'] = stages.get(f'{axis}_wait_forward_pixels_tables', 0) + t1 - t0
         stages[f'{axis}_enqueue_next_forward'] = stages.get(f'{axis}_enqueue_next_forward', 0) + t2 - t1
-        stages[f'{axis}_tracking'] = stages.get(f'{axis}_tracking', 0) + time.perf_counter() - t2
-    n_found, vol = 0, None
-    if trackers['xy'] is not None:                   # rank 0 holds the stitched trackers
-        t0 = time.perf_counter()
-        cons, vols = sharded.consensus_volume(trackers, shape3d, LABELS, ENGINE['thing_list'],
+        stages[f'{axis}_chain_and_lift'] = stages.get(f'{axis}_chain_and_lift', 0) + time.perf_counter() - t2
+    t0 = time.perf_counter()
+    cons, vols, zs = sharded.consensus_volume(planes, shape3d, LABELS, ENGINE['thing_list'],
                                               CONSENSUS['pixel_vote_thr'], CONSENSUS['cluster_iou_thr'],
                                               CONSENSUS['bypass'], FILTERS['min_size'], FILTERS['min_span'])
-        t1 = time.perf_counter()
-        vol = vols[1]
-        if host_out is not None:
-            host_out.copy_(vol.view(torch.int32), non_blocking=True)
-            torch.cuda.current_stream().synchronize()      # the post stream only: a prefetched forward keeps running
-        stages['consensus_and_fill'] = stages.get('consensus_and_fill', 0) + t1 - t0
-        stages['to_host'] = stages.get('to_host', 0) + time.perf_counter() - t1
-        n_found = len(cons[1].instances)
-    return n_found, vol
+    t1 = time.perf_counter()
+    vol = vols[1]
+    if host_out is not None:
+        host_out.copy_(vol.view(torch.int32), non_blocking=True)
+        torch.cuda.current_stream().synchronize()      # the post stream only: a prefetched forward keeps running
+    stages['consensus_and_fill'] = stages.get('consensus_and_fill', 0) + t1 - t0
+    stages['to_host'] = stages.get('to_host', 0) + time.perf_counter() - t1
+    return int(cons[1].alive.sum()), vol, zs
 
 
-def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages, first=None, prefetch_next=False):
+def orthoplane_step(pipe, stacks, heads, shape3d, host_out, stages, first=None, prefetch_next=False):
     """One pass.  Two HIP streams: the forward of plane p+1 is queued (default stream) as soon as the device tables of
     plane p are on the host; the host half of plane p and its device work run on the post-processing stream meanwhile.
     With prefetch_next the xy forward of the NEXT pass is queued the same way behind the yz tables, so that the tail
@@ -392,7 +402,7 @@ def orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages, firs
             return dict.__getitem__(self, axis)
 
     with torch.cuda.stream(post):
-        n_found, _ = postprocess_planes(_Heads(heads), shape3d, slice0, host_out, stages, between)
+        n_found, _, _ = postprocess_planes(_Heads(heads), shape3d, host_out, stages, between)
     torch.cuda.current_stream().wait_stream(post)
     return state['chk'], n_found, state['next']
 
@@ -448,7 +458,7 @@ def cpu_baseline_ortho(args, n, cores):
     dt = time.perf_counter() - t0
     # the HIP path on exactly the same heads
     dev_heads = {a: {k: v.cuda().contiguous() for k, v in heads[a].items()} for a in heads}
-    _, vol = postprocess_planes(dev_heads, shape, 0, None, {})
+    _, vol, _ = postprocess_planes(dev_heads, shape, None, {})
     got = vol.view(torch.int32).cpu().numpy().astype(np.uint32)
     pq, n_gt, n_pred, n_match = volume_pq(ref, got)
     return {'value': round(float(n) ** 3 / dt / 1e6, 4), 'unit': 'Mvox/s', 'cores': cores, 'kind': 'port',
@@ -469,7 +479,9 @@ def main_orthoplane(args, device, rank, world):
     if not args.no_tune:
         pipe.tune(S, args.save_tune, args.load_tune)
     shape3d = (S, S, S)
-    host_out = torch.empty(shape3d, dtype=torch.int32).pin_memory() if rank == 0 else None
+    from empanada_amd.inference.sharded import shard_bounds
+    zb = shard_bounds(S, world)                      # every rank paints and copies out its own z-slab of the output
+    host_out = torch.empty((int(zb[rank + 1] - zb[rank]), S, S), dtype=torch.int32).pin_memory()
 
     def barrier():
         torch.cuda.synchronize()
@@ -478,7 +490,7 @@ def main_orthoplane(args, device, rank, world):
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, {})
+        orthoplane_step(pipe, stacks, heads, shape3d, host_out, {})
         log(f'warmup {i} done')
     barrier()
     _hip.PROFILE = {}
@@ -487,7 +499,7 @@ def main_orthoplane(args, device, rank, world):
     t0 = time.perf_counter()
     first = None
     for k in range(args.steps):
-        chk, n_found, first = orthoplane_step(pipe, stacks, heads, slice0, shape3d, host_out, stages, first,
+        chk, n_found, first = orthoplane_step(pipe, stacks, heads, shape3d, host_out, stages, first,
                                               prefetch_next=(k + 1 < args.steps) and not args.no_pipeline)
         chks.append(chk)
     barrier()

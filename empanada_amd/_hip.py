@@ -81,6 +81,14 @@ SIGNATURES = {
     'emp_fill_table_u32': (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     'emp_scatter_yz_u32': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     'emp_fill_runs_u8': (_I, [_P, _L, _P, _P, _L, _c.c_uint8, _P]),
+    'emp_track_work_elems': (_L, [_L]),
+    'emp_track_lift': (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, _P]),
+    'emp_track_lift_yz': (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _I, _L, _P, _P, _P]),
+    'emp_track_sort_work_bytes': (_L, [_L]),
+    'emp_track_sort': (_I, [_P, _P, _L, _I, _P, _L, _P, _P, _P, _P, _P]),
+    'emp_track_offsets': (_I, [_P, _L, _L, _P, _P]),
+    'emp_track_expand': (_I, [_P, _P, _L, _L, _P, _P]),
+    'emp_track_clip': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -249,6 +249,8 @@ __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *__restrict__ vo
         int64_t s = starts[r], e = s + lens[r];
         if (s < 0) s = 0;
         if (e > n_vox) e = n_vox;
+        if (ids[order[r]] == 0) continue;          // id 0 = instance removed by a filter: it paints nothing and
+                                                   // does not shadow the instances below it
         uint32_t tag = FILL_TAG | (uint32_t)order[r];
         for (int64_t v = s + lane; v < e; v += 64) {
             if (PASS == 0) {

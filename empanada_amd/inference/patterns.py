@@ -36,7 +36,7 @@ __all__ = [
     'update_trackers', 'finish_tracking', 'apply_filters', 'get_axis_trackers_by_class',
     'create_instance_consensus', 'create_semantic_consensus', 'fill_volume', 'fill_panoptic_volume',
     'all_gather', 'forward_multigpu', 'harden_seg', 'get_panoptic_seg',
-    'track_stack', 'fill_volume_device', 'tables_from_stack', 'chain_from_tables', 'merge_partial_trackers',
+    'track_stack', 'fill_volume_device', 'tables_from_stack', 'chain_from_tables',
 ]
 
 
@@ -467,13 +467,16 @@ def chain_from_tables(host, D, labels, thing_list, label_divisor, merge_iou_thr=
 
 
 def track_stack(pan, axis_name, shape3d, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25,
-                return_table=False, timers=None):
+                return_table=False, timers=None, as_tracks=False):
     """Panoptic label stack of one plane (D,H,W uint32, device) -> finished InstanceTrackers, one per label.
 
     Equivalent to, slice by slice: pan_seg_to_rle_seg(force_connected=True) -> apply_matchers (forward) ->
     backward_matching -> update_trackers -> finish_tracking (scripts/pdl_inference3d.py:163-198).
+    The runs never leave the device until the trackers are asked for (device_tracks.PlaneTracks.trackers());
+    as_tracks=True returns the PlaneTracks itself (what the consensus of the whole-stack path consumes).
     """
     import time
+    from . import device_tracks as DT
     _t = [time.perf_counter()]
 
     def _lap(name):
@@ -489,125 +492,13 @@ def track_stack(pan, axis_name, shape3d, labels, thing_list, label_divisor, merg
     _lap('runs_cc_overlaps_to_host')
     comp_final, first_seen = chain_from_tables(host, D, labels, thing_list, label_divisor, merge_iou_thr, merge_ioa_thr)
     _lap('matching_chain')
-    trackers = _assemble_trackers(table, comp_final, host['c_slice'], host['c_cls'], host['c_box'], first_seen,
-                                  axis_name, shape3d, labels, label_divisor)
-    _lap('assemble_trackers')
+    tracks = DT.plane_tracks(table, host, comp_final, first_seen, axis_name, shape3d, labels, label_divisor)
+    _lap('lift_runs')
+    if as_tracks:
+        return (tracks, table, comp_final) if return_table else tracks
+    trackers = tracks.trackers()
+    _lap('materialise_trackers')
     return (trackers, table, comp_final) if return_table else trackers
-
-
-def _assemble_trackers(table, comp_final, c_slice, c_cls, c_box, first_seen, axis_name, shape3d, labels,
-                       label_divisor, slice0=0):
-    """Build the InstanceTracker.instances dicts (tracker.py:61-123 semantics) from the run table and the final
-    component labels with vectorised numpy over the O(#runs) table.
-
-    slice0: global index of the table's first slice (slice-sharded runs: the table holds a contiguous block of the
-    axis).  Components whose final label is 0 (halo slice, filtered) are skipped.  first_seen=None leaves the
-    instances in ascending label order (partial trackers; the merge on rank 0 orders them)."""
-    D, H, W = table.D, table.H, table.W
-    c_slice = c_slice + slice0
-    r_start = table.r_start.cpu().numpy().astype(np.int64)
-    r_len = table.r_len.cpu().numpy().astype(np.int64)
-    r_comp = table.r_comp.cpu().numpy()
-    trackers = []
-    n_runs = len(r_start)
-    r_slice = c_slice[r_comp] if n_runs else np.zeros(0, np.int64)
-    r_label = comp_final[r_comp] if n_runs else np.zeros(0, np.int64)
-    r_cls = c_cls[r_comp] if n_runs else np.zeros(0, np.int64)
-    for l in labels:
-        tr = InstanceTracker(l, label_divisor, shape3d, axis_name)
-        sel = np.flatnonzero((r_cls == l) & (r_label > 0))
-        if len(sel):
-            sl, lb, st, ln = r_slice[sel], r_label[sel], r_start[sel], r_len[sel]
-            # runs of one (label, slice) in start order; slices descending (backward pass order)
-            o = np.lexsort((st, -sl, lb))
-            sl, lb, st, ln = sl[o], lb[o], st[o], ln[o]
-            # merge runs that touch inside one (label, slice): rle_encode / join_ranges result
-            brk = np.ones(len(st), dtype=bool)
-            brk[1:] = (lb[1:] != lb[:-1]) | (sl[1:] != sl[:-1]) | (st[1:] != st[:-1] + ln[:-1])
-            seg = np.flatnonzero(brk)
-            st, sl, lb = st[seg], sl[seg], lb[seg]
-            ln = np.add.reduceat(ln, seg)
-            Z, Y, X = shape3d
-            if axis_name == 'xy':
-                st3 = st + sl * (H * W)
-                ln3 = ln
-            elif axis_name == 'xz':           # 2D plane (Z, X): only the run START is mapped (tracker.py:78-82)
-                st3 = (st // W) * (Y * X) + sl * X + (st % W)
-                ln3 = ln
-            else:
-                # 2D plane (Z, Y), slices along x: the reference decodes every pixel to a unit run and, at finish(),
-                # sorts and re-encodes them (tracker.py:83-88,110-113) -- i.e. the RLE along x of the dense labelling.
-                # The GPU scatters the labels into a (Z, Y, X) volume and reads the runs back with the row-run kernels.
-                cval = np.where(c_cls == l, comp_final, 0)
-                st3, ln3, lb = _hip.yz_runs_along_x(table, _hip.np_to_dev_u32(cval), shape3d, slice0)
-                o2 = np.argsort(lb, kind='stable')                                       # by label, voxel order inside
-                st3, ln3, lb = st3[o2], ln3[o2], lb[o2]
-                b2 = np.ones(len(st3), dtype=bool)
-                b2[1:] = (lb[1:] != lb[:-1]) | (st3[1:] != st3[:-1] + ln3[:-1])          # runs touching across row ends merge
-                s2 = np.flatnonzero(b2)
-                ln3 = np.add.reduceat(ln3, s2) if len(s2) else ln3
-                st3, lb = st3[s2], lb[s2]
-            cuts = np.flatnonzero(np.diff(lb)) + 1
-            lab_vals = lb[np.concatenate([[0], cuts])]
-            st_parts = np.split(st3, cuts)
-            ln_parts = np.split(ln3, cuts)
-            # boxes: merge of the per-slice 3D boxes of the member components (to_box3d + merge_boxes)
-            csel = np.flatnonzero((c_cls == l) & (comp_final > 0))
-            cl = comp_final[csel]
-            co = np.argsort(cl, kind='stable')
-            cl, cb, csl = cl[co], c_box[csel][co].astype(np.int64), c_slice[csel][co]
-            bc = np.concatenate([[0], np.flatnonzero(np.diff(cl)) + 1])
-            lo2 = np.minimum.reduceat(cb[:, :2], bc, axis=0)
-            hi2 = np.maximum.reduceat(cb[:, 2:], bc, axis=0)
-            s_lo = np.minimum.reduceat(csl, bc)
-            s_hi = np.maximum.reduceat(csl, bc) + 1
-            boxes = {}
-            for lab, (h1, w1), (h2, w2), a0, a1 in zip(cl[bc].tolist(), lo2.tolist(), hi2.tolist(), s_lo.tolist(),
-                                                         s_hi.tolist()):
-                if axis_name == 'xy':
-                    boxes[lab] = (a0, h1, w1, a1, h2, w2)
-                elif axis_name == 'xz':
-                    boxes[lab] = (h1, a0, w1, h2, a1, w2)
-                else:
-                    boxes[lab] = (h1, w1, a0, h2, w2, a1)
-            inst = {int(lab): {'box': boxes[int(lab)], 'starts': s, 'runs': r}
-                    for lab, s, r in zip(lab_vals, st_parts, ln_parts)}
-            for lab in (sorted(inst, key=lambda k: first_seen[l][k]) if first_seen is not None else sorted(inst)):
-                tr.instances[lab] = inst[lab]
-        tr.finished = True
-        trackers.append(tr)
-    return trackers
-
-
-def merge_partial_trackers(partials, first_seen, axis_name, shape3d, labels, label_divisor):
-    """Stitch the partial trackers of consecutive slice blocks (in ascending block order) into the trackers the
-    reference builds over the whole axis.  xy / xz: the per-slice run lists are concatenated in descending slice
-    order, i.e. later blocks first (update order of backward_matching, patterns.py:115-121); yz: the voxel runs
-    along x of all blocks are merged where they touch (= sort + re-encode of tracker.py:110-113)."""
-    out = []
-    for li, l in enumerate(labels):
-        tr = InstanceTracker(l, label_divisor, shape3d, axis_name)
-        acc = {}
-        for part in reversed(partials):
-            for lab, a in part[li].instances.items():
-                e = acc.setdefault(lab, {'box': a['box'], 'starts': [], 'runs': []})
-                e['box'] = merge_boxes(a['box'], e['box'])
-                e['starts'].append(a['starts'])
-                e['runs'].append(a['runs'])
-        for lab in sorted(acc, key=lambda k: first_seen[l][k]):
-            e = acc[lab]
-            st, ln = np.concatenate(e['starts']), np.concatenate(e['runs'])
-            if axis_name == 'yz' and len(e['starts']) > 1:
-                o = np.argsort(st, kind='stable')
-                st, ln = st[o], ln[o]
-                brk = np.ones(len(st), dtype=bool)
-                brk[1:] = st[1:] != st[:-1] + ln[:-1]
-                seg = np.flatnonzero(brk)
-                st, ln = st[seg], np.add.reduceat(ln, seg)
-            tr.instances[lab] = {'box': tuple(int(b) for b in e['box']), 'starts': st, 'runs': ln}
-        tr.finished = True
-        out.append(tr)
-    return out
 
 
 def fill_volume_device(shape3d, trackers, dtype=torch.uint32):

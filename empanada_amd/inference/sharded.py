@@ -1,37 +1,43 @@
-"""Slice-sharded stack inference across the GPUs of one node: one process per GPU, torch.distributed over
-RCCL (backend 'nccl' on ROCm), contiguous slice blocks per rank.
+"""Slice-sharded inference across the GPUs of one node: one process per GPU, torch.distributed over RCCL (backend
+'nccl' on ROCm), contiguous slice blocks per rank -- of every plane, over ONE shared volume.
 
-What the reference does (scripts/inference3d_multigpu.py:353-375, inference/patterns.py:226-240): strided
-slices per rank, an all_gather of `sem` and `cells` after EVERY slice, and one CPU process on rank 0 that
-does median -> fusion -> CC -> RLE -> matching for the whole stack.
+What the reference does (scripts/inference3d_multigpu.py:353-375, inference/patterns.py:226-240): strided slices per
+rank, an all_gather of `sem` and `cells` after EVERY slice, and one CPU process on rank 0 that does median -> fusion ->
+CC -> RLE -> matching for the whole stack.
 
-What this module does instead (MI355X-first):
+What this module does instead (MI355X-first; no rank is special, nothing is pickled, no pixels through the host):
   1. every rank runs the model on its own contiguous block of slices (no communication);
-  2. ONE all-gather of the semantic probabilities per plane, so that each rank can run the recursive median
-     (serial in z by definition, engines.py:68-90) over the whole axis -- elementwise and ~0.1 ms per 256 slices;
+  2. the recursive median (serial in z by definition, engines.py:68-90) is handed over from rank to rank: rank r
+     receives the last ks//2 FILTERED probability slices of rank r-1 and the first ks//2 RAW slices of rank r+1
+     (point-to-point over xGMI, 4 MiB per slice at 1024^2), filters its block and passes its own tail on.  The chain
+     is serial but each link costs ~0.2 ms; memory stays O(block);
   3. centres, grouping, fusion, runs, connected components: local, on the rank's own slices;
   4. a one-slice halo (first label slice of the next rank) gives the overlaps across block borders;
-  5. only O(#objects) tables travel to rank 0, which runs the label-propagation chain once and broadcasts
-     the final label of every component; each rank paints its own z-slab of the output volume.
-No per-slice synchronisation, no pixels through the host.  The host logic (steps 4-5) is plain numpy +
-torch.distributed object collectives and is covered on CPU with the gloo backend (tests/test_sharded_gloo.py).
+  5. the O(#components) tables are all-gathered as ONE padded int64 tensor and EVERY rank runs the (deterministic)
+     label-propagation chain over the whole axis -- replicated host work instead of gather-to-0 + broadcast;
+  6. stack mode: each rank paints its own z-slab.  Orthoplane mode: each rank lifts the 3D runs of its slices on the
+     device (device_tracks.py); for the consensus the runs of all planes are all-gathered (~20 MB per plane at 1024^3),
+     clipped to the rank's z-slab of the OUTPUT volume, and every rank votes, paints and copies out its own slab;
+     pair intersections and voted areas are summed with two small all-reduces, the graph logic is replicated.
+Host logic is covered on CPU with the gloo backend (tests/test_sharded_gloo.py).
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from .. import _hip
-from .patterns import _assemble_trackers, chain_from_tables, merge_partial_trackers, tables_from_stack
+from . import device_tracks as DT
+from .patterns import chain_from_tables, tables_from_stack
 from .postprocess import centers_batched
 
-__all__ = ['shard_bounds', 'merge_rank_tables', 'filter_labels', 'gather_tables_and_chain', 'sharded_panoptic_stack',
-           'sharded_tables', 'fill_slab', 'sharded_stack_volume', 'partial_trackers', 'sharded_track_plane', 'finish_plane',
-           'consensus_volume']
+__all__ = ['shard_bounds', 'merge_rank_tables', 'filter_labels', 'gather_tables_and_chain', 'chain_over_ranks',
+           'median_handover', 'sharded_panoptic_stack', 'sharded_tables', 'fill_slab', 'sharded_stack_volume',
+           'track_plane', 'finish_plane', 'gather_plane_runs', 'gather_plane_tracks', 'consensus_volume']
 
 
-def _world():
+def _world(group=None):
     if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+        return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
 
 
@@ -115,47 +121,109 @@ def filter_labels(host, comp_final, min_size=None, min_span=None):
     return out
 
 
-def gather_tables_and_chain(local_host, n_local, labels, thing_list, label_divisor, merge_iou_thr=0.25,
-                            merge_ioa_thr=0.25, min_size=None, min_span=None, group=None, return_first_seen=False):
-    """Steps 4-5 of the module docstring.  Every rank passes its local tables (own slices + halo); rank 0 merges
-    them, runs the chain over the whole axis and the size/span filters, and every rank receives the final label
-    of each of its own components (0 = filtered out; halo components get 0)."""
-    rank, world = _world()
+# ----------------------------------------------------------------------------- collectives on tables
+def _staged(t, group):
+    """gloo cannot move device tensors: rehearsal runs (several ranks on one GPU) stage through the host"""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def _gather_var(t, group=None):
+    """all-gather of tensors whose first dimension differs per rank: one count all-gather + ONE padded
+    all_gather_into_tensor; returns the per-rank tensors on t's device."""
+    rank, world = _world(group)
+    if world == 1:
+        return [t]
+    nccl = dist.get_backend(group) == 'nccl'
+    dev = t.device
+    w = t.contiguous() if (nccl or not t.is_cuda) else t.contiguous().cpu()
+    if nccl and not w.is_cuda:
+        w = w.cuda()
+    n = torch.tensor([w.shape[0]], dtype=torch.int64, device=w.device)
+    counts = torch.zeros((world,), dtype=torch.int64, device=w.device)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts = counts.cpu().tolist()
+    mx = max(max(counts), 1)
+    pad = torch.zeros((mx,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    pad[:w.shape[0]] = w
+    out = torch.empty((world * mx,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return [out[r * mx:r * mx + counts[r]].to(dev) for r in range(world)]
+
+
+def _all_reduce_sum(a, group=None):
+    """int64 numpy vector summed over the ranks"""
+    rank, world = _world(group)
+    if world == 1 or len(a) == 0:
+        return a
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
+    if dist.get_backend(group) == 'nccl':
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
+_COLS = ('c_slice', 'c_label', 'c_area', 'c_cls')
+
+
+def _pack_tables(host, n_local):
+    """component + overlap tables of one rank as one flat int64 vector: [n_local, n, k, 8 n comp columns, 3 k trips]"""
+    n = len(host['c_slice'])
+    cols = [np.asarray(host[c], dtype=np.int64).reshape(n, 1) for c in _COLS]
+    cols.append(np.asarray(host['c_box'], dtype=np.int64).reshape(n, 4))
+    trip = np.asarray(host['trip'], dtype=np.int64).reshape(-1, 3)
+    return np.concatenate([np.array([n_local, n, len(trip)], dtype=np.int64), np.concatenate(cols, axis=1).ravel(),
+                           trip.ravel()])
+
+
+def _unpack_tables(flat):
+    flat = np.asarray(flat, dtype=np.int64)
+    n_local, n, k = (int(x) for x in flat[:3])
+    comp = flat[3:3 + 8 * n].reshape(n, 8)
+    host = {c: comp[:, i].copy() for i, c in enumerate(_COLS)}
+    host['c_box'] = comp[:, 4:8].astype(np.int32)
+    host['trip'] = flat[3 + 8 * n:3 + 8 * n + 3 * k].reshape(k, 3).copy()
+    return host, n_local
+
+
+def chain_over_ranks(local_host, n_local, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25,
+                     group=None):
+    """Steps 4-5 of the module docstring.  Every rank passes its local tables (own slices + one halo slice) and
+    receives the same result: (tables of the whole axis, final label per component, first_seen, index of each of its
+    local components in the whole-axis tables with -1 for halo components, first slice of its block)."""
+    rank, world = _world(group)
+    labels, thing_list = list(labels), list(thing_list)
     if world == 1:
         final, first_seen = chain_from_tables(local_host, n_local, labels, thing_list, label_divisor, merge_iou_thr,
                                               merge_ioa_thr)
-        final = filter_labels(local_host, final, min_size, min_span)
-        return (final, first_seen) if return_first_seen else final
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (local_host, int(n_local)), group=group)
-    result = [None]
-    first_seen = None
-    if rank == 0:
-        tables = [g[0] for g in gathered]
-        counts = np.array([g[1] for g in gathered], dtype=np.int64)
-        merged, own_index = merge_rank_tables(tables, counts)
-        final, first_seen = chain_from_tables(merged, int(counts.sum()), labels, thing_list, label_divisor,
-                                              merge_iou_thr, merge_ioa_thr)
-        final = filter_labels(merged, final, min_size, min_span)
-        per_rank = []
-        for idx in own_index:
-            v = np.zeros(len(idx), dtype=np.int64)
-            v[idx >= 0] = final[idx[idx >= 0]]
-            per_rank.append(v)
-        result = [per_rank]
-    dist.broadcast_object_list(result, src=0, group=group)
-    final = result[0][rank]
-    return (final, first_seen) if return_first_seen else final
+        return local_host, final, first_seen, np.arange(len(final), dtype=np.int64), 0
+    parts = _gather_var(torch.from_numpy(_pack_tables(local_host, n_local)), group)
+    tables, counts = zip(*[_unpack_tables(p.cpu().numpy()) for p in parts])
+    counts = np.array(counts, dtype=np.int64)
+    merged, own_index = merge_rank_tables(list(tables), counts)
+    final, first_seen = chain_from_tables(merged, int(counts.sum()), labels, thing_list, label_divisor, merge_iou_thr,
+                                          merge_ioa_thr)
+    return merged, final, first_seen, own_index[rank], int(counts[:rank].sum())
+
+
+def gather_tables_and_chain(local_host, n_local, labels, thing_list, label_divisor, merge_iou_thr=0.25,
+                            merge_ioa_thr=0.25, min_size=None, min_span=None, group=None, return_first_seen=False):
+    """Stack mode: chain over the whole axis + size / span filters; every rank gets the final label of each of its
+    own components (0 = filtered out; halo components get 0)."""
+    merged, final, first_seen, own, _ = chain_over_ranks(local_host, n_local, labels, thing_list, label_divisor,
+                                                         merge_iou_thr, merge_ioa_thr, group)
+    final = filter_labels(merged, final, min_size, min_span)
+    mine = np.zeros(len(own), dtype=np.int64)
+    mine[own >= 0] = final[own[own >= 0]]
+    return (mine, first_seen) if return_first_seen else mine
 
 
 # ----------------------------------------------------------------------------- device side
 def _all_gather_cat(t, group=None):
     """all_gather of equally shaped device tensors, concatenated along dim 0 (RCCL all-gather over xGMI)."""
-    rank, world = _world()
+    rank, world = _world(group)
     if world == 1:
         return t
-    if t.is_cuda and dist.get_backend(group) == 'gloo':
-        # rehearsal mode (several ranks on one GPU, `EMP_BENCH_BACKEND=gloo`): stage through the host
+    if _staged(t, group):
         parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
         dist.all_gather(parts, t.contiguous().cpu(), group=group)
         return torch.cat(parts, dim=0).to(t.device)
@@ -164,18 +232,55 @@ def _all_gather_cat(t, group=None):
     return out
 
 
+def _send(t, dst, group):
+    dist.send(t.contiguous().cpu() if _staged(t, group) else t.contiguous(), dst, group=group)
+
+
+def _recv(shape, dtype, device, src, group):
+    staged = device.type == 'cuda' and dist.get_backend(group) == 'gloo'
+    buf = torch.empty(shape, dtype=dtype, device='cpu' if staged else device)
+    dist.recv(buf, src, group=group)
+    return buf.to(device)
+
+
+def median_handover(prob_local, ks, thr, group=None, median=None):
+    """Recursive median + harden of a rank's block of probabilities (D_local, C, H, W) with the exact whole-axis
+    result: out[t] = median(out[t-m .. t-1], x[t .. t+m]) (engines.py:68-84), first / last m slices of the AXIS raw.
+    The kernel passes the first m slices of whatever stack it is given through unchanged and uses them as history, so
+    prepending rank r-1's last m filtered slices (and appending rank r+1's first m raw ones) reproduces the recursion
+    bit for bit.  Block sizes may differ; every block must hold at least m slices.  Returns sem (D_local, H, W) u8."""
+    median = median or _hip.median_harden_stack
+    rank, world = _world(group)
+    m = (int(ks) - 1) // 2
+    if world == 1 or m == 0:
+        return median(prob_local, ks, thr)
+    D = prob_local.shape[0]
+    assert D >= m, f"a block of {D} slices is shorter than the median's reach ({m})"
+    dev, tail = prob_local.device, tuple(prob_local.shape[1:])
+    # raw halo: my first m slices go left, the right neighbour's come in (independent of the recursion)
+    if rank > 0:
+        _send(prob_local[:m], rank - 1, group)
+    right = _recv((m,) + tail, prob_local.dtype, dev, rank + 1, group) if rank + 1 < world else None
+    left = _recv((m,) + tail, prob_local.dtype, dev, rank - 1, group) if rank > 0 else None
+    parts = [p for p in (left, prob_local, right) if p is not None]
+    ext = torch.cat(parts, dim=0)
+    sem, filt = median(ext, ks, thr, want_prob=True)
+    lo = m if rank > 0 else 0
+    if rank + 1 < world:
+        _send(filt[lo + D - m:lo + D], rank + 1, group)
+    return sem[lo:lo + D].contiguous()
+
+
 def sharded_panoptic_stack(sem_prob_local, ctr_hmp_local, offsets_local, *, thing_list, label_divisor=1000,
                            stuff_area=64, void_label=0, nms_threshold=0.1, nms_kernel=7, confidence_thr=0.5,
                            median_kernel_size=3, coarse_boundaries=True, n_classes=None, group=None):
-    """panoptic_stack for a rank's block of slices.  All ranks must hold the same number of slices (pad the
-    volume or use shard sizes that divide it).  Returns pan (D_local, Hp, Wp) uint32."""
-    rank, world = _world()
+    """panoptic_stack for a rank's block of slices (blocks may differ in size).  Returns pan (D_local, Hp, Wp) uint32."""
     D, C, Hp, Wp = sem_prob_local.shape
     ks = int(median_kernel_size)
-    full = _all_gather_cat(sem_prob_local.float().contiguous(), group)
-    assert full.shape[0] >= ks or ks == 1, "stack shorter than the median kernel"
-    sem_full = _hip.median_harden_stack(full, ks, confidence_thr)
-    sem = sem_full[rank * D:(rank + 1) * D].contiguous()
+    rank, world = _world(group)
+    if world == 1:
+        assert D >= ks or ks == 1, "stack shorter than the median kernel"
+    sem = median_handover(sem_prob_local.float().contiguous(), ks, confidence_thr, group)
     step = 4 if coarse_boundaries else 1
     idx, cnt = centers_batched(ctr_hmp_local, nms_threshold, nms_kernel)
     ids = _hip.group_pixels(idx, cnt, offsets_local.float().contiguous(), step,
@@ -187,9 +292,9 @@ def sharded_panoptic_stack(sem_prob_local, ctr_hmp_local, offsets_local, *, thin
 
 
 def sharded_tables(pan_local, labels, thing_list, label_divisor, group=None):
-    """Stack mode, step 3-4a (device): local runs / connected components and, through a one-slice halo (first
-    label slice of the next rank), the overlaps across the block border.  Returns (RunTable, host tables)."""
-    rank, world = _world()
+    """Local runs / connected components and, through a one-slice halo (first label slice of the next rank), the
+    overlaps across the block border.  Returns (RunTable, host tables)."""
+    rank, world = _world(group)
     pan_ext = pan_local
     if world > 1:
         firsts = _all_gather_cat(pan_local[:1].contiguous().view(torch.int32), group).view(torch.uint32)
@@ -200,7 +305,7 @@ def sharded_tables(pan_local, labels, thing_list, label_divisor, group=None):
 
 
 def fill_slab(table, final, shape_local):
-    """Stack mode, step 5 (device): paint the rank's (D_local, H, W) uint32 slab from its run table and the final
+    """Stack mode, step 6 (device): paint the rank's (D_local, H, W) uint32 slab from its run table and the final
     label of every component (0 = dropped)."""
     D, H, W = shape_local
     vol = torch.zeros((D, H, W), dtype=torch.int32, device=table.r_start.device).view(torch.uint32)
@@ -211,7 +316,7 @@ def fill_slab(table, final, shape_local):
 
 def sharded_stack_volume(pan_local, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25,
                          min_size=None, min_span=None, group=None):
-    """Stack mode, steps 3-5: local runs/CC, halo overlaps, global chain on rank 0, local slab fill.
+    """Stack mode, steps 3-6: local runs/CC, halo overlaps, replicated chain, local slab fill.
     Returns the rank's (D_local, H, W) uint32 slab of the labelled volume (device)."""
     table, host = sharded_tables(pan_local, labels, thing_list, label_divisor, group)
     final = gather_tables_and_chain(host, pan_local.shape[0], list(labels), list(thing_list), label_divisor,
@@ -220,71 +325,115 @@ def sharded_stack_volume(pan_local, labels, thing_list, label_divisor, merge_iou
 
 
 # ----------------------------------------------------------------------------- orthoplane: trackers per plane
-def partial_trackers(table, host, final_local, axis_name, shape3d, slice0, labels, label_divisor):
-    """The rank's share of one plane's trackers: 3D run lists of its own slices (global slice = slice0 + local),
-    instances in ascending label order.  Halo components carry label 0 and are skipped."""
-    return _assemble_trackers(table, np.asarray(final_local, dtype=np.int64), host['c_slice'], host['c_cls'],
-                              host['c_box'], None, axis_name, shape3d, list(labels), label_divisor, slice0=slice0)
+def finish_plane(table, host, n_local, axis_name, shape3d, labels, thing_list, label_divisor, merge_iou_thr=0.25,
+                 merge_ioa_thr=0.25, inst_base=0, group=None):
+    """Everything of a plane after its device tables exist: replicated chain over the whole axis, instance table,
+    lift of the rank's own runs into the (Z, Y, X) frame on the device.  Split from track_plane so that a driver can
+    queue the next plane's forward on the GPU first.  Returns PlaneTracks (instance table of the WHOLE axis, runs of
+    this rank's slices)."""
+    merged, final, first_seen, own, slice0 = chain_over_ranks(host, n_local, labels, thing_list, label_divisor,
+                                                              merge_iou_thr, merge_ioa_thr, group)
+    return DT.plane_tracks(table, merged, final, first_seen, axis_name, shape3d, list(labels), label_divisor,
+                           slice0=slice0, inst_base=inst_base, local_comp_index=own)
 
 
-def finish_plane(table, host, n_local, axis_name, shape3d, slice0, labels, thing_list, label_divisor,
-                 merge_iou_thr=0.25, merge_ioa_thr=0.25, group=None):
-    """Host half of sharded_track_plane (everything after the device tables exist): chain on rank 0, partial
-    trackers, all-gather of the RLE tables, stitch.  Split out so that a driver can queue the next plane's forward
-    on the GPU before calling it."""
-    rank, world = _world()
-    labels, thing_list = list(labels), list(thing_list)
-    final, first_seen = gather_tables_and_chain(host, n_local, labels, thing_list, label_divisor, merge_iou_thr,
-                                                merge_ioa_thr, group=group, return_first_seen=True)
-    part = partial_trackers(table, host, final, axis_name, shape3d, slice0, labels, label_divisor)
-    if world == 1:
-        return merge_partial_trackers([part], first_seen, axis_name, shape3d, labels, label_divisor)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, part, group=group)
-    if rank != 0:
-        return None
-    return merge_partial_trackers(gathered, first_seen, axis_name, shape3d, labels, label_divisor)
-
-
-def sharded_track_plane(pan_local, axis_name, shape3d, slice0, labels, thing_list, label_divisor, merge_iou_thr=0.25,
-                        merge_ioa_thr=0.25, group=None):
-    """Orthoplane mode, one plane: every rank passes the panoptic labels of its contiguous block of slices
-    (global index of the first one = slice0).  Steps: local runs / CC / halo overlaps, chain over the whole axis on
-    rank 0, per-rank partial trackers (the O(#runs) assembly is sharded too), all-gather of the partial per-instance
-    3D RLE tables -- the collective SURVEY 8(e) calls "Collective 2" -- and the stitch on rank 0.
-    Returns the plane's finished trackers on rank 0 (None on the other ranks)."""
+def track_plane(pan_local, axis_name, shape3d, labels, thing_list, label_divisor, merge_iou_thr=0.25,
+                merge_ioa_thr=0.25, inst_base=0, group=None):
+    """Orthoplane mode, one plane: every rank passes the panoptic labels of its contiguous block of slices."""
     table, host = sharded_tables(pan_local, list(labels), list(thing_list), label_divisor, group)
-    return finish_plane(table, host, pan_local.shape[0], axis_name, shape3d, slice0, labels, thing_list,
-                        label_divisor, merge_iou_thr, merge_ioa_thr, group)
+    return finish_plane(table, host, pan_local.shape[0], axis_name, shape3d, labels, thing_list, label_divisor,
+                        merge_iou_thr, merge_ioa_thr, inst_base, group)
 
 
-def consensus_volume(trackers_by_axis, shape3d, labels, thing_list, pixel_vote_thr=2, cluster_iou_thr=0.75,
-                     bypass=False, min_size=None, min_span=None):
-    """Orthoplane mode, last step, on the rank that holds the stitched trackers (rank 0): per-plane filters,
-    instance / semantic consensus per class, filters again, fill (scripts/pdl_inference3d.py:200-233).
-    trackers_by_axis: {'xy': [tracker per label], 'xz': [...], 'yz': [...]}.
-    Returns ({class: consensus tracker}, {class: labelled (Z,Y,X) device volume, uint32 for things / uint8 stuff})."""
-    from . import filters
-    from .patterns import (create_instance_consensus, create_semantic_consensus, fill_volume_device,
-                           get_axis_trackers_by_class)
-    for trs in trackers_by_axis.values():
-        for tr in trs:
-            if min_size is not None:
-                filters.remove_small_objects(tr, min_size)
-            if min_span is not None:
-                filters.remove_pancakes(tr, min_span)
+def gather_plane_runs(pt, group=None):
+    """all ranks' runs of one plane: (key, ln, n) device arrays, concatenated in rank order ("Collective 2" of SURVEY
+    8(e): one count all-gather + one padded all-gather of the flat (key, len) table)"""
+    rank, world = _world(group)
+    if world == 1:
+        return pt.key[:pt.n_runs], pt.ln[:pt.n_runs], pt.n_runs
+    local = torch.stack([pt.key[:pt.n_runs], pt.ln[:pt.n_runs]], dim=1)
+    allr = torch.cat(_gather_var(local, group), dim=0)
+    return allr[:, 0].contiguous(), allr[:, 1].contiguous(), int(allr.shape[0])
+
+
+def gather_plane_tracks(pt, group=None):
+    """PlaneTracks holding every run of the plane on every rank (for callers that want the reference's trackers:
+    pt.trackers()); yz runs split at block borders are joined again."""
+    rank, world = _world(group)
+    if world == 1:
+        return pt
+    key, ln, n = gather_plane_runs(pt, group)
+    out = DT.PlaneTracks(pt.axis, pt.shape3d, pt.labels, pt.label_divisor)
+    for name in ('inst_label', 'inst_cls', 'inst_area', 'inst_box', 'alive', 'inst_base'):
+        setattr(out, name, getattr(pt, name))
+    out.key, out.st, out.ln, out.n_runs = DT.sort_runs(key, ln, n, merge_touching=(pt.axis == 'yz'))
+    return out
+
+
+def consensus_volume(planes, shape3d, labels, thing_list, pixel_vote_thr=2, cluster_iou_thr=0.75, bypass=False,
+                     min_size=None, min_span=None, group=None):
+    """Orthoplane mode, last step (scripts/pdl_inference3d.py:200-233): per-plane filters, instance / semantic
+    consensus per class, filters again, fill -- sharded by z-slab of the OUTPUT volume.
+
+    planes: {'xy': PlaneTracks, 'xz': ..., 'yz': ...} whose instance indices are disjoint (inst_base) and ascending in
+    that order.  Every rank votes on and paints the flat voxel interval [z0 * Y * X, z1 * Y * X) of its own z-slab.
+    Returns ({class: ConsensusResult}, {class: (z1 - z0, Y, X) device slab, uint32 things / uint8 stuff}, (z0, z1))."""
+    from .. import consensus as CO
+    rank, world = _world(group)
+    Z, Y, X = (int(s) for s in shape3d)
+    zb = shard_bounds(Z, world)
+    z0, z1 = int(zb[rank]), int(zb[rank + 1])
+    lo, hi = z0 * Y * X, z1 * Y * X
+    order = [planes[a] for a in ('xy', 'xz', 'yz') if a in planes]
+    for pt in order:
+        if min_size is not None:
+            pt.remove_small_objects(min_size)
+        if min_span is not None:
+            pt.remove_pancakes(min_span)
+    # ---- the run store of this rank's slab: every plane's runs (all ranks'), clipped to the slab, sorted
+    n_obj = sum(pt.n_inst for pt in order)
+    bases = np.cumsum([0] + [pt.n_inst for pt in order])
+    for pt, b in zip(order, bases):
+        assert pt.inst_base == int(b), "planes must be lifted with consecutive instance bases (xy, xz, yz)"
+    keys, lens = [], []
+    for pt in order:
+        key, ln, n = gather_plane_runs(pt, group)
+        if world > 1:
+            key, ln, n = DT.clip_runs(key, ln, n, lo, hi)
+            if n:
+                key, _, ln, n = DT.sort_runs(key, ln, n)           # rank blocks are sorted, their concatenation is not
+        keys.append(key[:n])
+        lens.append(ln[:n])
+    key = torch.cat(keys) if len(keys) > 1 else keys[0]
+    ln = torch.cat(lens) if len(lens) > 1 else lens[0]
+    n_runs = int(key.numel())
+    dev = ln.device
+    off = torch.empty((n_obj + 1,), dtype=torch.int64, device=dev)
+    _hip.call('emp_track_offsets', _hip._ptr(key) if n_runs else None, n_runs, n_obj, _hip._ptr(off), _hip.stream())
+    st = torch.bitwise_and(key, (1 << DT.POS_BITS) - 1)
+    store = CO.RunStore(st, ln, off)
+    reduce = (lambda a: _all_reduce_sum(a, group)) if world > 1 else None
+    src = np.concatenate([np.full(pt.n_inst, i, dtype=np.int64) for i, pt in enumerate(order)])
+    boxes = np.concatenate([pt.inst_box for pt in order])
+    areas = np.concatenate([pt.inst_area for pt in order])
+    alive = np.concatenate([pt.alive for pt in order])
+    cls = np.concatenate([pt.inst_cls for pt in order])
     cons, vols = {}, {}
     for class_id in labels:
-        cts = get_axis_trackers_by_class(trackers_by_axis, class_id)
+        nodes = np.flatnonzero(alive & (cls == class_id))
         if class_id in thing_list:
-            con = create_instance_consensus(cts, pixel_vote_thr, cluster_iou_thr, bypass)
+            res = CO.consensus_objects(src[nodes], boxes[nodes], areas[nodes], store, len(order), pixel_vote_thr,
+                                       cluster_iou_thr, bypass, reduce=reduce, store_index=nodes)
             if min_size is not None:
-                filters.remove_small_objects(con, min_size)
+                res.remove_small_objects(min_size)
             if min_span is not None:
-                filters.remove_pancakes(con, min_span)
-            vols[class_id] = fill_volume_device(shape3d, [con])
+                res.remove_pancakes(min_span)
+            vol = torch.zeros(((z1 - z0) * Y * X,), dtype=torch.int32, device=dev).view(torch.uint32)
         else:
-            con = create_semantic_consensus(cts, pixel_vote_thr)
-            vols[class_id] = fill_volume_device(shape3d, [con], dtype=torch.uint8)
-        cons[class_id] = con
-    return cons, vols
+            res = CO.consensus_semantic(src[nodes], boxes[nodes], store, pixel_vote_thr, reduce=reduce,
+                                        store_index=nodes)
+            vol = torch.zeros(((z1 - z0) * Y * X,), dtype=torch.uint8, device=dev)
+        res.paint(vol, lo)
+        cons[class_id] = res
+        vols[class_id] = vol.reshape(z1 - z0, Y, X)
+    return cons, vols, (z0, z1)

@@ -378,7 +378,8 @@ int emp_vote_ranges(const int64_t *starts, const int64_t *ends, const int32_t *g
  *          fill_func / zarr_fill_instances         empanada/zarr_utils.py:49-58,88-175
  * Runs (starts, lens int64 into the flat volume) carry an order index (position of their
  * instance in dict order) and ids[order] is painted; where runs of different instances overlap
- * the later instance wins, as in the reference's sequential fill.  Ids must be < 2^31.          */
+ * the later instance wins, as in the reference's sequential fill.  Ids must be < 2^31; runs whose
+ * id is 0 are skipped (an instance deleted by a filter neither paints nor shadows).              */
 int emp_fill_runs_u32(uint32_t *vol, int64_t n_vox, const int64_t *starts, const int64_t *lens,
                       const int32_t *order, int64_t n_runs, const uint32_t *ids, void *stream);
 int emp_fill_runs_u8(uint8_t *vol, int64_t n_vox, const int64_t *starts, const int64_t *lens,
@@ -400,6 +401,51 @@ int emp_fill_table_u32(uint32_t *vol, int64_t HW, int n_slices, int slice0, cons
 int emp_scatter_yz_u32(uint32_t *vol, int Z, int Y, int X, const int32_t *r_start, const int32_t *r_len,
                        const int32_t *r_comp, const int32_t *c_slice, const uint32_t *value,
                        int64_t n_runs, void *stream);
+
+/* ---- T1 on the device: run table of a plane's slices -> per-instance 3D runs sorted by (instance, start) ------
+ * replaces InstanceTracker.update / finish        empanada/inference/tracker.py:61-123
+ *          to_coords3d                             empanada/inference/tracker.py:25-38
+ * and feeds merge_objects_from_trackers (empanada/consensus.py:348-469) and the fill without a host round trip.
+ * A 3D run is (key, len): key = instance << 40 | flat (z, y, x) start of the (Z, Y, X) volume; len in voxels.
+ * comp_inst[c] = instance index of component c of the run table (its position in the tracker's dict order), -1 =
+ * skip (halo slice, removed).  inst_base is added to every instance index (planes concatenated for the consensus).
+ *
+ * emp_track_lift  axis 0 (xy: plane (H, W) = (Y, X), slices along z): start3d = start + slice * Y * X;
+ *                 axis 1 (xz: plane (H, W) = (Z, X), slices along y): start3d = (start / W) * Y * X + slice * X +
+ *                 start % W -- only the START is mapped and the length kept, reproducing the row wrap of
+ *                 tracker.py:78-82.  Runs of one instance that are contiguous inside a slice are merged first (what
+ *                 rle_encode over the instance's pixels yields, array_utils.py:209-235).  slice = c_slice + slice0.
+ *                 Outputs hold at most n_runs entries; n_out is a device int32.  work: emp_track_work_elems(n_runs)
+ *                 int32.
+ * emp_track_lift_yz  for the yz plane the tracker is the run-length encoding along x of the dense labelling
+ *                 (tracker.py:83-88,110-113): scatter instance + 1 with emp_scatter_yz_u32 into a (Z, Y, Xl) volume,
+ *                 extract its row runs (emp_runs_count / _extract) and pass them here: start3d = row * X + x0 + x.
+ * emp_track_sort  stable radix sort by key; with merge_touching, runs of one instance whose previous end equals their
+ *                 start are joined (np.sort + rle_encode in tracker.finish).  Any of out_key / out_st (= key's low 40
+ *                 bits) may be NULL.  work: emp_track_sort_work_bytes(n) bytes.
+ * emp_track_offsets  CSR offsets of the instances in a sorted key array: out_off[k] = first run with instance >= k,
+ *                 k = 0 .. n_inst.
+ * emp_track_expand  out[i] = obj_val[instance that owns run i] (vote groups, fill order) from CSR offsets.
+ * emp_track_clip  the part of every run inside the flat interval [lo, hi): a rank's z-slab of the output volume
+ *                 (chunk_ranges, empanada/zarr_utils.py:11-47, splits runs at chunk borders the same way).
+ *                 work: emp_track_work_elems(n) int32.                                                        */
+int64_t emp_track_work_elems(int64_t n_runs);
+int emp_track_lift(int axis, const int32_t *r_start, const int32_t *r_len, const int32_t *r_comp,
+                   const int32_t *c_slice, const int32_t *comp_inst, int64_t n_runs, int H, int W, int Y, int X,
+                   int slice0, int64_t inst_base, int32_t *work, uint64_t *out_key, int64_t *out_len,
+                   int32_t *n_out, void *stream);
+int emp_track_lift_yz(const int32_t *row_offsets, const int32_t *r_start, const int32_t *r_len,
+                      const uint32_t *r_val, int64_t n_rows, int64_t n_runs, int Xl, int X, int x0,
+                      int64_t inst_base, uint64_t *out_key, int64_t *out_len, void *stream);
+int64_t emp_track_sort_work_bytes(int64_t n);
+int emp_track_sort(const uint64_t *key_in, const int64_t *len_in, int64_t n, int merge_touching, void *work,
+                   int64_t work_bytes, uint64_t *out_key, int64_t *out_st, int64_t *out_len, int32_t *n_out,
+                   void *stream);
+int emp_track_offsets(const uint64_t *keys_sorted, int64_t n, int64_t n_inst, int64_t *out_off, void *stream);
+int emp_track_expand(const int64_t *off, const int32_t *obj_val, int64_t n_obj, int64_t n_runs, int32_t *out,
+                     void *stream);
+int emp_track_clip(const uint64_t *key, const int64_t *len, int64_t n, int64_t lo, int64_t hi, int32_t *work,
+                   uint64_t *out_key, int64_t *out_len, int32_t *n_out, void *stream);
 
 /* ---- M4/M5 (host): slice-to-slice label propagation over component tables, plain C++ on the CPU ---------
  * replaces RLEMatcher.__call__ driven by forward_matching / backward_matching

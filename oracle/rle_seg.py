@@ -206,6 +206,32 @@ def forward_matching(pan_segs, matchers, labels, label_divisor, thing_list):
     return rle_stack
 
 
+def forward_multigpu(items, matchers, confidence_thr, median_kernel_size, labels, label_divisor, thing_list,
+                     stuff_area=32, void_label=0):
+    """patterns.py:279-350 without the mp.Queue / Pipe: items = [(sem probabilities (1,C,H,W), instance cells
+    (1,1,H,W)), ...] in arrival order; median queue over 'sem' -> harden -> get_panoptic_seg -> rle_seg ->
+    apply_matchers.  Returns the rle_stack the reference sends through the pipe."""
+    from . import postprocess as OP
+    q = OP.MedianQueue(median_kernel_size)
+    rle_stack = []
+
+    def consume(o):
+        sem = OP.harden_seg(o['sem'], confidence_thr)[0]
+        pan = OP.get_panoptic_seg(sem, np.asarray(o['cells'], dtype=np.float32), label_divisor, thing_list,
+                                  stuff_area, void_label)
+        rle_seg = pan_seg_to_rle_seg(pan.squeeze(), labels, label_divisor, thing_list, force_connected=True)
+        rle_stack.append(apply_matchers(rle_seg, matchers))
+
+    for sem, cells in items:
+        q.enqueue({'sem': np.asarray(sem, dtype=np.float32), 'cells': cells})
+        o = q.get_next(['sem'])
+        if o is not None:
+            consume(o)
+    for o in q.end():
+        consume(o)
+    return rle_stack
+
+
 def backward_matching(rle_stack, matchers, axis_len):
     """patterns.py:102-121 -- generator over slices n-1..0, assign_new=False, stack mutated in place."""
     for m in matchers:

@@ -185,3 +185,52 @@ def test_consensus_kats():
             strs.append(tr)
         inst = OC.merge_semantic_from_trackers(strs, int(g[f's{j}_vote']))
         assert_instances_equal(inst, unpack_instances(g, f's{j}_inst'))
+
+
+def _mg_case(g, i):
+    """inputs of forward_multigpu fixture i, regenerated from its seeds (oracle/gen_golden_r2.py)"""
+    from empanada_amd import synthetic as SY
+    C, ks, seed, n_out = (int(x) for x in g[f'c{i}_par'])
+    nthing = 1 if C == 1 else C - 1
+    lab, cls = SY.planted_labels((9, 56, 64), fill=0.25, rmin=4, rmax=9, seed=seed, n_classes=nthing)
+    heads = SY.planted_heads(lab, cls, 'xy', n_classes=nthing, seed=seed)
+    labels = [1] if C == 1 else [1, 2]
+    return heads, ks, labels, n_out
+
+
+def test_get_panoptic_segmentation_golden():
+    """P6: oracle get_panoptic_segmentation against the reference's outputs (postprocess.py:298-356)"""
+    from empanada_amd import synthetic as SY
+    g = load_golden('panoptic_seg')
+    for i in range(int(g['n'])):
+        C, k, seed = (int(x) for x in g[f'c{i}_par'])
+        thr = float(g[f'c{i}_thr'])
+        lab, cls = SY.planted_labels((3, 72, 88), fill=0.25, rmin=4, rmax=10, seed=seed, n_classes=max(C - 1, 1))
+        heads = SY.planted_heads(lab, cls, 'xy', n_classes=1 if C == 1 else C - 1, seed=seed)
+        for z in range(3):
+            prob = heads['sem'][z:z + 1].numpy()
+            sem = OP.harden_seg(prob, 0.5)
+            pan, ctr = OP.get_panoptic_segmentation(sem, heads['ctr_hmp'][z:z + 1].numpy(),
+                                                    heads['offsets'][z:z + 1].numpy(), [1], 1000, 16, 0, thr, k)
+            np.testing.assert_array_equal(pan, g[f'c{i}_z{z}_pan'], err_msg=f'{i} {z}')
+            np.testing.assert_array_equal(ctr, g[f'c{i}_z{z}_ctr'], err_msg=f'{i} {z}')
+            assert len(np.unique(pan)) > 2
+
+
+def test_forward_multigpu_golden():
+    """forward_multigpu (patterns.py:279-350): the oracle's restatement against the rle_stack the reference sent"""
+    g = load_golden('forward_multigpu')
+    for i in range(int(g['n'])):
+        heads, ks, labels, n_out = _mg_case(g, i)
+        items = []
+        for z in range(heads['sem'].shape[0]):
+            cells = OP.get_instance_cells(heads['ctr_hmp'][z:z + 1].numpy(), heads['offsets'][z:z + 1].numpy(), 0.1, 7,
+                                          False)
+            items.append((heads['sem'][z:z + 1].numpy(), cells))
+        matchers = OS.create_matchers([1], 1000, 0.25, 0.25)
+        stack = OS.forward_multigpu(items, matchers, 0.5, ks, labels, 1000, [1], 16, 0)
+        assert len(stack) == n_out
+        for z, rs in enumerate(stack):
+            exp = unpack_rle_seg(g, f'c{i}_z{z}')
+            for c in labels:
+                assert_instances_equal(rs[c], exp.get(c, {}))

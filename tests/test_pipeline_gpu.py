@@ -193,6 +193,22 @@ def test_whole_stack_pipeline_matches_reference():
             host = np.zeros(lab.shape, dtype=np.uint32)
             PA.fill_volume(host, cons[cid].instances)
             np.testing.assert_array_equal(host, g[f'p{i}_vol{cid}'])
+        # the device-resident route bench.py takes: PlaneTracks -> consensus on tables -> paint, nothing on the host
+        dcons, dvols = run_device_pipeline(pans, lab.shape, labels, thing)
+        for cid in labels:
+            assert_instances_equal(dcons[cid].instances(), unpack_instances(g, f'p{i}_con{cid}'))
+            np.testing.assert_array_equal(dvols[cid].cpu().numpy().astype(np.uint32), g[f'p{i}_vol{cid}'])
+
+
+def run_device_pipeline(pans, shape, labels, thing, min_size=100, min_span=3, div=1000):
+    from empanada_amd.inference import sharded
+    planes, base = {}, 0
+    for name in ('xy', 'xz', 'yz'):
+        planes[name] = sharded.track_plane(pans[name], name, shape, labels, thing, div, 0.25, 0.25, inst_base=base)
+        base += planes[name].n_inst
+    cons, vols, (z0, z1) = sharded.consensus_volume(planes, shape, labels, thing, 2, 0.75, False, min_size, min_span)
+    assert (z0, z1) == (0, shape[0])
+    return cons, vols
 
 
 def test_consensus_kats():
@@ -434,10 +450,12 @@ def test_sharded_path_world1_equals_tracker_path():
     np.testing.assert_array_equal(got, exp)
 
 
-def test_partial_trackers_stitch_equals_whole_axis():
+def test_block_lifted_runs_equal_whole_axis():
     """slice-sharded orthoplane tracking, all three axes, without the collectives: two 'virtual ranks' build their
-    tables (with halo), the tables are merged and chained as on rank 0, each block assembles its partial trackers
-    and the stitch reproduces track_stack over the whole axis (which the reference fixtures pin)."""
+    tables (with halo), the tables are merged and chained as every rank does, each block lifts the runs of its own
+    slices with the instance indices of the whole axis, and the concatenation (sorted; yz pieces split at the block
+    border joined again) is exactly the run set of track_stack over the whole axis (which the reference fixtures pin)."""
+    from empanada_amd.inference import device_tracks as DT
     from empanada_amd.inference import patterns as PA
     from empanada_amd.inference import sharded
     from empanada_amd.inference.postprocess import panoptic_stack
@@ -449,7 +467,8 @@ def test_partial_trackers_stitch_equals_whole_axis():
         pan, _ = panoptic_stack(heads['sem'].cuda(), heads['ctr_hmp'].cuda(), heads['offsets'].cuda(),
                                 thing_list=thing, label_divisor=1000, stuff_area=16, void_label=0, nms_threshold=0.1,
                                 nms_kernel=7, confidence_thr=0.5, median_kernel_size=3, coarse_boundaries=False)
-        whole = PA.track_stack(pan, name, shape, labels, thing, 1000, 0.25, 0.25)
+        whole = PA.track_stack(pan, name, shape, labels, thing, 1000, 0.25, 0.25, as_tracks=True)
+        assert whole.n_inst > 5
         D = pan.shape[0]
         for cut in (D // 2, 7):
             bounds = [0, cut, D]
@@ -462,18 +481,21 @@ def test_partial_trackers_stitch_equals_whole_axis():
             counts = np.array([cut, D - cut])
             merged, own = sharded.merge_rank_tables(hosts, counts)
             final, first_seen = PA.chain_from_tables(merged, D, labels, thing, 1000, 0.25, 0.25)
-            parts = []
-            for r in range(2):
-                fl = np.zeros(len(own[r]), dtype=np.int64)
-                fl[own[r] >= 0] = final[own[r][own[r] >= 0]]
-                parts.append(sharded.partial_trackers(tabs[r], hosts[r], fl, name, shape, bounds[r], labels, 1000))
-            stitched = PA.merge_partial_trackers(parts, first_seen, name, shape, labels, 1000)
-            for a, b in zip(stitched, whole):
-                assert a.class_id == b.class_id
-                assert_instances_equal(a.instances, b.instances)
-        # world = 1 through the public entry point
-        solo = sharded.sharded_track_plane(pan, name, shape, 0, labels, thing, 1000)
-        for a, b in zip(solo, whole):
+            parts = [DT.plane_tracks(tabs[r], merged, final, first_seen, name, shape, labels, 1000, slice0=bounds[r],
+                                     local_comp_index=own[r]) for r in range(2)]
+            for part in parts:
+                np.testing.assert_array_equal(part.inst_label, whole.inst_label)
+                np.testing.assert_array_equal(part.inst_box, whole.inst_box)
+                np.testing.assert_array_equal(part.inst_area, whole.inst_area)
+            key = torch.cat([part.key[:part.n_runs] for part in parts])
+            ln = torch.cat([part.ln[:part.n_runs] for part in parts])
+            k2, st2, l2, n2 = DT.sort_runs(key, ln, int(key.numel()), merge_touching=(name == 'yz'))
+            assert n2 == whole.n_runs
+            assert torch.equal(k2[:n2], whole.key[:n2]) and torch.equal(l2[:n2], whole.ln[:n2])
+            assert torch.equal(st2[:n2], whole.st[:n2])
+        # the materialised trackers against the whole-axis tracker objects
+        solo = sharded.track_plane(pan, name, shape, labels, thing, 1000)
+        for a, b in zip(solo.trackers(), whole.trackers()):
             assert_instances_equal(a.instances, b.instances)
 
 
@@ -513,3 +535,104 @@ def test_evaluator_on_tracker_jsons(tmp_path):
     inter = np.count_nonzero((lab_gt > 0) & (lab_pr > 0)); union = np.count_nonzero((lab_gt > 0) | (lab_pr > 0))
     assert res['iou'] == inter / union
     assert ev(paths[0], paths[0])['pq'] == pytest.approx(1.0, abs=1e-4)
+
+
+def test_get_panoptic_segmentation_golden():
+    """P6 (postprocess.py:298-356): shape checks + centres + grouping + fusion in one call, against the reference"""
+    from empanada_amd.inference.postprocess import get_panoptic_segmentation
+    g = load_golden('panoptic_seg')
+    for i in range(int(g['n'])):
+        C, k, seed = (int(x) for x in g[f'c{i}_par'])
+        thr = float(g[f'c{i}_thr'])
+        lab, cls = SY.planted_labels((3, 72, 88), fill=0.25, rmin=4, rmax=10, seed=seed, n_classes=max(C - 1, 1))
+        heads = SY.planted_heads(lab, cls, 'xy', n_classes=1 if C == 1 else C - 1, seed=seed)
+        for z in range(3):
+            prob = heads['sem'][z:z + 1]
+            sem = (prob >= 0.5).long() if C == 1 else torch.argmax(prob, dim=1, keepdim=True)
+            pan, ctr = get_panoptic_segmentation(sem.cuda(), heads['ctr_hmp'][z:z + 1].cuda(),
+                                                 heads['offsets'][z:z + 1].cuda(), [1], 1000, 16, 0, thr, k)
+            assert pan.dtype == torch.int64 and ctr.dtype == torch.int64
+            np.testing.assert_array_equal(pan.cpu().numpy(), g[f'c{i}_z{z}_pan'], err_msg=f'{i} {z}')
+            np.testing.assert_array_equal(ctr.cpu().numpy(), g[f'c{i}_z{z}_ctr'], err_msg=f'{i} {z}')
+    with pytest.raises(ValueError):
+        get_panoptic_segmentation(torch.zeros((1, 2, 8, 8)).cuda(), torch.zeros((1, 1, 8, 8)).cuda(),
+                                  torch.zeros((1, 2, 8, 8)).cuda(), [1], 1000, 16, 0)
+    with pytest.raises(ValueError):
+        get_panoptic_segmentation(torch.zeros((2, 1, 8, 8), dtype=torch.long).cuda(), torch.zeros((2, 1, 8, 8)).cuda(),
+                                  torch.zeros((2, 2, 8, 8)).cuda(), [1], 1000, 16, 0)
+
+
+class _ListQueue:
+    def __init__(self, items):
+        self.items = list(items)
+
+    def get(self):
+        return self.items.pop(0)
+
+
+class _Sink:
+    sent = None
+
+    def send(self, obj):
+        self.sent = obj
+
+    def close(self):
+        pass
+
+
+def test_forward_multigpu_golden():
+    """patterns.forward_multigpu (patterns.py:279-350) fed through a queue like the matcher process of
+    scripts/inference3d_multigpu.py: the rle_stack it sends equals the reference's"""
+    from conftest import unpack_rle_seg
+    from empanada_amd.inference import engines as EN
+    from empanada_amd.inference import patterns as PA
+    g = load_golden('forward_multigpu')
+    for i in range(int(g['n'])):
+        C, ks, seed, n_out = (int(x) for x in g[f'c{i}_par'])
+        nthing = 1 if C == 1 else C - 1
+        lab, cls = SY.planted_labels((9, 56, 64), fill=0.25, rmin=4, rmax=9, seed=seed, n_classes=nthing)
+        heads = SY.planted_heads(lab, cls, 'xy', n_classes=nthing, seed=seed)
+        labels = [1] if C == 1 else [1, 2]
+        eng = EN.PanopticDeepLabRenderEngine(torch.nn.Identity(), thing_list=[1], label_divisor=1000, nms_kernel=7,
+                                             nms_threshold=0.1, confidence_thr=0.5, coarse_boundaries=False)
+        items = []
+        for z in range(lab.shape[0]):
+            cells = eng.get_instance_cells(heads['ctr_hmp'][z:z + 1].cuda(), heads['offsets'][z:z + 1].cuda())
+            items.append((heads['sem'][z:z + 1].cuda(), cells))
+        items.append(('finish', 'finish'))
+        sink = _Sink()
+        PA.forward_multigpu(PA.create_matchers([1], 1000, 0.25, 0.25), _ListQueue(items), [], sink, 0.5, ks, labels,
+                            1000, [1], 16, 0)
+        stack = sink.sent[0]
+        assert len(stack) == n_out
+        for z, rs in enumerate(stack):
+            exp = unpack_rle_seg(g, f'c{i}_z{z}')
+            for c in labels:
+                assert_instances_equal(rs[c], exp.get(c, {}))
+
+
+def test_logits_to_prob_gpu_vs_cpu_at_the_threshold():
+    """D2 (engines.py:22-30) is torch on either side: sigmoid / softmax on the GPU against the same call on the CPU.
+    What matters downstream is the hardening decision `p >= thr` (engines.py:114-121) and the argmax: checked on a
+    dense sweep of logits around logit(thr) for the thresholds the configs use, and on random multi-class logits.
+    The probabilities themselves may differ in the last place (different exp implementations); the bound is asserted."""
+    from empanada_amd.inference.engines import logits_to_prob
+    gen = torch.Generator().manual_seed(0)
+    for thr in (0.3, 0.5):
+        centre = float(np.log(thr / (1 - thr)))
+        near = centre + (torch.rand((1, 1, 1024, 2048), generator=gen) - 0.5) * 2e-3
+        exact = torch.full((1, 1, 1, 16), centre)
+        wide = (torch.rand((1, 1, 1024, 2048), generator=gen) - 0.5) * 16
+        for x in (near, exact, wide):
+            cpu = logits_to_prob(x)
+            gpu = logits_to_prob(x.cuda()).cpu()
+            ulp = (gpu.view(torch.int32) - cpu.view(torch.int32)).abs().max().item()
+            assert ulp <= 2, ulp
+            flips = int(((gpu >= thr) != (cpu >= thr)).sum())
+            # a flip needs |p - thr| below one ulp of p: record how often that happens on 2M logits within 1e-3
+            assert flips <= 4, (thr, flips)
+    x = torch.randn((1, 5, 512, 512), generator=gen) * 3
+    cpu = logits_to_prob(x)
+    gpu = logits_to_prob(x.cuda()).cpu()
+    assert (gpu - cpu).abs().max().item() <= 5e-7
+    assert int((gpu.argmax(dim=1) != cpu.argmax(dim=1)).sum()) == 0

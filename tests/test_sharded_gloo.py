@@ -167,72 +167,50 @@ def test_host_chain_against_reference_goldens():
 
 
 # ------------------------------------------------------------------------------------------------ orthoplane
-class _FakeTable:
-    """CPU twin of _hip.RunTable (torch tensors on the host) for the numpy assembly code."""
-
-
-def cpu_run_table(pan_shape, comp_maps, host):
-    D, H, W = pan_shape
-    rs, rl, rc = [], [], []
-    for d in range(D):
-        cm = comp_maps[d].reshape(H, W)
-        for y in range(H):
-            row = cm[y]
-            x = 0
-            while x < W:
-                if row[x] >= 0:
-                    x1 = x
-                    while x1 < W and row[x1] == row[x]:
-                        x1 += 1
-                    rs.append(y * W + x); rl.append(x1 - x); rc.append(int(row[x]))
-                    x = x1
-                else:
-                    x += 1
-    t = _FakeTable()
-    t.D, t.H, t.W = D, H, W
-    t.r_start = torch.tensor(rs, dtype=torch.int32)
-    t.r_len = torch.tensor(rl, dtype=torch.int32)
-    t.r_comp = torch.tensor(rc, dtype=torch.int32)
-    t.c_slice = torch.from_numpy(host['c_slice'].astype(np.int32))
-    t.n_runs, t.n_comp = len(rs), len(host['c_slice'])
-    return t
-
-
 def _worker_plane(rank, world, port, bounds, axis_name, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
+        from empanada_amd.inference import device_tracks as DT
         pan = make_stack(seed=5)
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         ext = pan[lo:hi + 1] if rank + 1 < world else pan[lo:hi]
-
-        def fake_tables(pan_local, labels, thing_list, label_divisor, group=None):
-            host, maps = cpu_tables(ext, list(labels), list(thing_list))
-            return cpu_run_table(ext.shape, maps, host), host
-        sharded.sharded_tables = fake_tables
-        shape3d = pan.shape if axis_name == 'xy' else (pan.shape[1], pan.shape[0], pan.shape[2])
-        trs = sharded.sharded_track_plane(torch.zeros((hi - lo, 1, 1)), axis_name, shape3d, lo, [1, 2], [1], DIV)
-        q.put((rank, None if trs is None else [{k: (v['box'], v['starts'], v['runs']) for k, v in t.instances.items()}
-                                                for t in trs]))
+        host, maps = cpu_tables(ext, [1, 2], [1])
+        merged, final, first_seen, own, slice0 = sharded.chain_over_ranks(host, hi - lo, [1, 2], [1], DIV, 0.25, 0.25)
+        lab, cls, area, box, comp_inst = DT.instance_table(merged, final, first_seen, axis_name, [1, 2])
+        mine = np.where(own >= 0, comp_inst[np.maximum(own, 0)], -1)       # instance of each local component
+        q.put((rank, dict(final=final, lab=lab, cls=cls, area=area, box=box, slice0=slice0,
+                          painted=paint(maps[:hi - lo], np.where(mine >= 0, lab[np.maximum(mine, 0)], 0)),
+                          seen={k: list(v.items()) for k, v in first_seen.items()})))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('axis_name', ['xy', 'xz'])
-def test_two_rank_plane_trackers_equal_single_rank(axis_name):
-    """sharded_track_plane over gloo (tables -> rank-0 chain -> partial trackers -> all_gather_object -> stitch)
-    against the same functions on one rank.  The device half is replaced by its numpy twin (no GPU here); the yz
-    scatter path is covered on the GPU (tests/test_pipeline_gpu.py::test_partial_trackers_stitch...)."""
-    from empanada_amd.inference.patterns import _assemble_trackers
+@pytest.mark.parametrize('axis_name', ['xy', 'xz', 'yz'])
+@pytest.mark.parametrize('split', [(6, 8), (9, 5)])
+def test_two_rank_replicated_chain_and_instance_tables(axis_name, split):
+    """chain_over_ranks over gloo (ONE padded all-gather of the packed tables, chain replicated on every rank) and
+    the instance table built from it: both ranks hold exactly what a single rank computes over the whole axis --
+    labels, dict order, 3D boxes, voxel counts -- and each rank's own components map to the right instances."""
+    from empanada_amd.inference import device_tracks as DT
     pan = make_stack(seed=5)
-    shape3d = pan.shape if axis_name == 'xy' else (pan.shape[1], pan.shape[0], pan.shape[2])
     host, maps = cpu_tables(pan, [1, 2], [1])
     final, first_seen = chain_from_tables(host, pan.shape[0], [1, 2], [1], DIV, 0.25, 0.25)
-    table = cpu_run_table(pan.shape, maps, host)
-    whole = _assemble_trackers(table, final, host['c_slice'], host['c_cls'], host['c_box'], first_seen, axis_name,
-                               shape3d, [1, 2], DIV)
-    bounds = np.array([0, 6, pan.shape[0]])
+    lab, cls, area, box, comp_inst = DT.instance_table(host, final, first_seen, axis_name, [1, 2])
+    assert len(lab) > 3
+    # the table against a direct evaluation on the painted volume (slices along the plane's normal)
+    vol = paint(maps, final).reshape(pan.shape)
+    k = {'xy': 0, 'xz': 1, 'yz': 2}[axis_name]
+    for i in range(len(lab)):
+        ss, rr, cc = np.nonzero((vol == lab[i]) & (pan // DIV == cls[i]))
+        assert area[i] == len(ss)
+        lo3 = [rr.min(), cc.min()]
+        hi3 = [rr.max() + 1, cc.max() + 1]
+        lo3.insert(k, ss.min())
+        hi3.insert(k, ss.max() + 1)
+        assert list(box[i]) == lo3 + hi3
+    bounds = np.concatenate([[0], np.cumsum(split)])
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -243,14 +221,59 @@ def test_two_rank_plane_trackers_equal_single_rank(axis_name):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got[1] is None
-    assert sum(len(t.instances) for t in whole) > 3
-    for tr, g in zip(whole, got[0]):
-        assert list(tr.instances.keys()) == list(g.keys())
-        for k, a in tr.instances.items():
-            assert tuple(a['box']) == tuple(g[k][0])
-            np.testing.assert_array_equal(a['starts'], g[k][1])
-            np.testing.assert_array_equal(a['runs'], g[k][2])
+    for r in range(2):
+        g = got[r]
+        np.testing.assert_array_equal(g['final'], final)
+        for name, exp in (('lab', lab), ('cls', cls), ('area', area), ('box', box)):
+            np.testing.assert_array_equal(g[name], exp)
+        assert g['seen'] == {k2: list(v.items()) for k2, v in first_seen.items()}
+        assert g['slice0'] == int(bounds[r])
+    np.testing.assert_array_equal(np.concatenate([got[0]['painted'], got[1]['painted']]), paint(maps, final))
+
+
+def _median_twin(prob, ks, thr, want_prob=False):
+    """numpy statement of the recursive median + harden (engines.py:68-90, 114-121) with the kernel's interface"""
+    x = prob.numpy()
+    D = x.shape[0]
+    m = (ks - 1) // 2
+    out = x.copy()
+    for t in range(m, D - m):
+        out[t] = np.median(np.concatenate([out[t - m:t], x[t:t + m + 1]]), axis=0)
+    sem = torch.from_numpy((out[:, 0] >= thr).astype(np.uint8))
+    return (sem, torch.from_numpy(out)) if want_prob else sem
+
+
+def _worker_median(rank, world, port, bounds, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        x = torch.from_numpy(np.random.default_rng(7).random((int(bounds[-1]), 1, 6, 5)).astype(np.float32))
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        q.put((rank, sharded.median_handover(x[lo:hi], 7, 0.5, median=_median_twin).numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('split', [(7, 7), (3, 11), (4, 5, 5), (3, 3, 3, 5)])
+def test_median_handover_equals_whole_axis(split):
+    """the rank-to-rank hand-over of filtered history + raw halo reproduces the recursive whole-axis median bit for
+    bit, for equal and unequal blocks down to the minimum block size (ks // 2 slices)"""
+    bounds = np.concatenate([[0], np.cumsum(split)])
+    x = torch.from_numpy(np.random.default_rng(7).random((int(bounds[-1]), 1, 6, 5)).astype(np.float32))
+    exp = _median_twin(x, 7, 0.5).numpy()
+    world = len(split)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_median, args=(r, world, port, bounds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(np.concatenate([got[r] for r in range(world)]), exp)
 
 
 def _blobby_stack(seed, shape=(40, 48, 56), n=60):
