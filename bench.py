@@ -9,7 +9,8 @@ full pass of the hot path over the volume (scripts/pdl_inference3d.py:110-233 in
   for each plane xy / xz / yz: PanopticDeepLab-R50 forward over every slice (fp32, synthesised weights, resident uint8
   volume) -> sigmoid -> recursive median + harden -> centres -> pixel grouping -> semantic/instance fusion -> runs +
   8-connected components -> slice-to-slice overlaps -> forward/backward label propagation -> 3D trackers -> size/span
-  filters;  then instance consensus over the three planes -> filters -> labelled uint32 volume in pinned host memory.
+  filters;  then instance consensus over the three planes -> filters -> labelled uint32 volume written to a zarr v2
+  array chunked (1, Y, X) (scripts/pdl_inference3d.py:225-233).
 `--mode stack` keeps round 1's xy-only stack workload (configs[1], 256x512x512, no consensus).
 
 Inputs are resident in HBM when the timed region starts (uint8 EM volume + planted head tensors, see
@@ -27,7 +28,9 @@ import argparse
 import json
 import os
 import subprocess
+import shutil
 import sys
+import tempfile
 import threading
 import time
 
@@ -109,6 +112,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-forward-check', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='run the passes strictly one after the other')
+    ap.add_argument('--out', default=None, help='zarr v2 directory the labelled volume is written to (default: a '
+                    'scratch store under /dev/shm)')
+    ap.add_argument('--keep-out', action='store_true', help='do not delete the output store at the end')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel of the forward from Python (no HIP graph)')
     args = ap.parse_args()
     if args.steps is None:
@@ -328,10 +334,10 @@ def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None):
 
 
 # ----------------------------------------------------------------------------------------------- orthoplane
-def postprocess_planes(heads, shape3d, host_out, stages, between=None):
+def postprocess_planes(heads, shape3d, writer, stages, between=None):
     """The part of a pass that follows the forwards, for all three planes (heads[axis] = the rank's block of head
     tensors): per plane pixels -> tables -> chain (replicated on every rank) -> device-resident trackers, then filters
-    -> consensus -> filters -> fill of the rank's z-slab -> pinned host memory.  `between(i)` is called once plane
+    -> consensus -> filters -> fill of the rank's z-slab -> pinned host memory -> zarr chunk files.  `between(i)` is called once plane
     i's device tables are on the host (the driver queues the next forward there).
     Returns (#consensus instances, the rank's slab of the labelled volume on the device, (z0, z1))."""
     from empanada_amd.inference import sharded
@@ -357,15 +363,17 @@ def postprocess_planes(heads, shape3d, host_out, stages, between=None):
                                               CONSENSUS['bypass'], FILTERS['min_size'], FILTERS['min_span'])
     t1 = time.perf_counter()
     vol = vols[1]
-    if host_out is not None:
-        host_out.copy_(vol.view(torch.int32), non_blocking=True)
+    if writer is not None:                             # slab -> pinned host buffer -> chunk files of the zarr array
+        buf = writer.next_buffer()                     # (written by a thread pool while the GPU runs the next pass)
+        buf.copy_(vol.view(torch.int32), non_blocking=True)
         torch.cuda.current_stream().synchronize()      # the post stream only: a prefetched forward keeps running
+        writer.submit()
     stages['consensus_and_fill'] = stages.get('consensus_and_fill', 0) + t1 - t0
-    stages['to_host'] = stages.get('to_host', 0) + time.perf_counter() - t1
+    stages['to_host_and_submit_write'] = stages.get('to_host_and_submit_write', 0) + time.perf_counter() - t1
     return int(cons[1].alive.sum()), vol, zs
 
 
-def orthoplane_step(pipe, stacks, heads, shape3d, host_out, stages, first=None, prefetch_next=False):
+def orthoplane_step(pipe, stacks, heads, shape3d, writer, stages, first=None, prefetch_next=False):
     """One pass.  Two HIP streams: the forward of plane p+1 is queued (default stream) as soon as the device tables of
     plane p are on the host; the host half of plane p and its device work run on the post-processing stream meanwhile.
     With prefetch_next the xy forward of the NEXT pass is queued the same way behind the yz tables, so that the tail
@@ -402,7 +410,7 @@ def orthoplane_step(pipe, stacks, heads, shape3d, host_out, stages, first=None, 
             return dict.__getitem__(self, axis)
 
     with torch.cuda.stream(post):
-        n_found, _, _ = postprocess_planes(_Heads(heads), shape3d, host_out, stages, between)
+        n_found, _, _ = postprocess_planes(_Heads(heads), shape3d, writer, stages, between)
     torch.cuda.current_stream().wait_stream(post)
     return state['chk'], n_found, state['next']
 
@@ -480,8 +488,17 @@ def main_orthoplane(args, device, rank, world):
         pipe.tune(S, args.save_tune, args.load_tune)
     shape3d = (S, S, S)
     from empanada_amd.inference.sharded import shard_bounds
-    zb = shard_bounds(S, world)                      # every rank paints and copies out its own z-slab of the output
-    host_out = torch.empty((int(zb[rank + 1] - zb[rank]), S, S), dtype=torch.int32).pin_memory()
+    from empanada_amd.zarr_utils import SlabWriter, ZarrV2Group, open_zarr
+    zb = shard_bounds(S, world)                      # every rank paints, copies out and WRITES its own z-slab
+    out_dir = args.out or os.path.join('/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir(),
+                                       f'emp_bench_{os.environ.get("MASTER_PORT", os.getpid())}.zarr')
+    if rank == 0:                                    # scripts/pdl_inference3d.py:228-231
+        ZarrV2Group(out_dir).create_dataset('mito_pred', shape=shape3d, dtype=np.uint32, overwrite=True,
+                                            chunks=(1, None, None))
+    if world > 1:
+        dist.barrier()
+    dataset = open_zarr(os.path.join(out_dir, 'mito_pred'))
+    writer = SlabWriter(dataset, int(zb[rank]), (int(zb[rank + 1] - zb[rank]), S, S), torch.int32, threads=4)
 
     def barrier():
         torch.cuda.synchronize()
@@ -490,7 +507,7 @@ def main_orthoplane(args, device, rank, world):
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        orthoplane_step(pipe, stacks, heads, shape3d, host_out, {})
+        orthoplane_step(pipe, stacks, heads, shape3d, writer, {})
         log(f'warmup {i} done')
     barrier()
     _hip.PROFILE = {}
@@ -499,9 +516,10 @@ def main_orthoplane(args, device, rank, world):
     t0 = time.perf_counter()
     first = None
     for k in range(args.steps):
-        chk, n_found, first = orthoplane_step(pipe, stacks, heads, shape3d, host_out, stages, first,
+        chk, n_found, first = orthoplane_step(pipe, stacks, heads, shape3d, writer, stages, first,
                                               prefetch_next=(k + 1 < args.steps) and not args.no_pipeline)
         chks.append(chk)
+    writer.drain()                                   # the last pass's chunk files are on disk
     barrier()
     dt = time.perf_counter() - t0
     log(f'timed {args.steps} steps in {dt:.2f}s')
@@ -511,8 +529,13 @@ def main_orthoplane(args, device, rank, world):
         t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    writer.close()
     if rank != 0:
         return
+    written = open_zarr(os.path.join(out_dir, 'mito_pred'))
+    mid = written[S // 2]                            # read one slice back from the store
+    out_check = {'path': out_dir, 'dataset': 'mito_pred', 'chunks': list(written.chunks), 'dtype': str(written.dtype),
+                 'labels_in_slice_read_back': int(len(np.unique(mid)) - 1)}
     chks = [float(c) for c in chks]
     vox_launch = float(S) ** 3 / world               # voxels one post-processing launch covers (a rank's block of a plane)
     thing_frac = float((heads['xy']['sem'] >= ENGINE['confidence_thr']).float().mean().item())
@@ -529,7 +552,7 @@ def main_orthoplane(args, device, rank, world):
                                f'forward on every slice of every plane + HIP post-processing on planted heads '
                                f'(ks=7, full-res heads), {n_obj} planted objects, slices of every plane sharded over '
                                f'{world} rank(s)',
-                   'mode': 'orthoplane', 'size': S, 'objects_found': int(n_found),
+                   'mode': 'orthoplane', 'size': S, 'objects_found': int(n_found), 'output': out_check,
                    'batch': pipe.slices_per_call(S, S)},
         'breakdown': {'stages_s_per_step': {k: round(v / args.steps, 4) for k, v in stages.items()},
                       'hand_written_dense_ms_per_pass_rank0': round(fwd_ms_pass, 1),
@@ -550,6 +573,8 @@ def main_orthoplane(args, device, rank, world):
         res['cpu_baseline'] = cpu_baseline_ortho(args, min(args.cpu_size, S), min(16, os.cpu_count() or 1))
     else:
         res['cpu_baseline'] = None
+    if not args.keep_out and args.out is None:
+        shutil.rmtree(out_dir, ignore_errors=True)
     print(json.dumps(res), flush=True)
 
 

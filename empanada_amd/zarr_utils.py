@@ -7,13 +7,19 @@ slice get/set (a zarr.Array, or a numpy array wrapped by ``ChunkedArray``) is ac
 at chunk borders with vectorised integer arithmetic (same ranges as the reference's per-index loop) and each
 chunk is painted on the GPU (emp_fill_runs_u32).
 """
+import json
 import math
+import os
+import shutil
+import zlib
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 from .array_utils import numpy_fill_instances, put, rle_to_ranges, take
 
-__all__ = ['zarr_fill_instances', 'chunk_ranges', 'zarr_put3d', 'zarr_take3d', 'ChunkedArray', 'ZarrData']
+__all__ = ['zarr_fill_instances', 'chunk_ranges', 'zarr_put3d', 'zarr_take3d', 'ChunkedArray', 'ZarrData',
+           'ZarrV2Group', 'ZarrV2Array', 'open_zarr', 'SlabWriter']
 
 
 class ChunkedArray:
@@ -128,3 +134,220 @@ class ZarrData:
         if self.tfs is not None:
             image = self.tfs(image=image)['image']
         return {'index': idx, 'image': image}
+
+
+# ----------------------------------------------------------------------------- zarr v2 directory store
+# The reference ends in `zarr_store.create_dataset(name, shape=shape, dtype=dtype, overwrite=True,
+# chunks=(1, None, None))` + `fill_volume` (scripts/pdl_inference3d.py:225-233).  The zarr package is not installed in
+# this image, so the v2 directory-store format is written directly (it is the published spec: a `.zgroup` /
+# `.zarray` JSON document per node and one file per chunk named by its dot-separated chunk index, C order,
+# little-endian, edge chunks padded to the full chunk shape with fill_value).  Compressor: none (raw bytes -- the
+# labelled slab goes from pinned memory to the file at memcpy speed) or stdlib zlib ({"id": "zlib"}, a numcodecs
+# codec every zarr reader has).  zarr's own default, Blosc, needs the blosc library and is not produced here; files
+# written by zarr with Blosc cannot be read here either (KeyError naming the codec).
+class ZarrV2Array:
+    """One array of a zarr v2 directory store: shape / chunks / dtype attributes, slice get / set (whole chunks are
+    read, modified and written back: what zarr_fill_instances needs), and `write_chunks` for bulk writes."""
+
+    def __init__(self, path, meta=None):
+        self.path = path
+        if meta is None:
+            with open(os.path.join(path, '.zarray')) as fh:
+                meta = json.load(fh)
+        if meta.get('zarr_format') != 2:
+            raise ValueError(f"{path}: zarr_format {meta.get('zarr_format')} is not 2")
+        comp = meta.get('compressor')
+        if comp is not None and comp.get('id') != 'zlib':
+            raise KeyError(f"{path}: compressor {comp.get('id')!r} is not available here (none or zlib only)")
+        if meta.get('filters'):
+            raise KeyError(f"{path}: filters are not supported")
+        if meta.get('order', 'C') != 'C':
+            raise ValueError(f"{path}: only C order is supported")
+        self.meta = meta
+        self.shape = tuple(meta['shape'])
+        self.chunks = tuple(meta['chunks'])
+        self.dtype = np.dtype(meta['dtype'])
+        self.fill_value = meta.get('fill_value') or 0
+        self.sep = meta.get('dimension_separator', '.')
+        self.zlib_level = None if comp is None else int(comp.get('level', 1))
+        self.nchunks = math.prod(math.ceil(s / c) for s, c in zip(self.shape, self.chunks))
+
+    # -- chunk files
+    def _chunk_path(self, idx):
+        return os.path.join(self.path, self.sep.join(str(i) for i in idx))
+
+    def read_chunk(self, idx):
+        p = self._chunk_path(idx)
+        if not os.path.exists(p):
+            return np.full(self.chunks, self.fill_value, dtype=self.dtype)
+        with open(p, 'rb') as fh:
+            raw = fh.read()
+        if self.zlib_level is not None:
+            raw = zlib.decompress(raw)
+        return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks).copy()
+
+    def write_chunk(self, idx, data):
+        """data: full chunk-shaped C-contiguous array (or anything with the buffer protocol of that size)"""
+        buf = memoryview(np.ascontiguousarray(data, dtype=self.dtype)).cast('B')
+        if buf.nbytes != self.dtype.itemsize * math.prod(self.chunks):
+            raise ValueError("write_chunk needs a full chunk")
+        p = self._chunk_path(idx)
+        with open(p, 'wb') as fh:
+            fh.write(zlib.compress(buf, self.zlib_level) if self.zlib_level is not None else buf)
+
+    # -- slicing (basic slices with step 1, ints)
+    def _norm(self, key):
+        if not isinstance(key, tuple):
+            key = (key,)
+        if any(k is Ellipsis for k in key):
+            i = [k is Ellipsis for k in key].index(True)
+            key = key[:i] + (slice(None),) * (len(self.shape) - len(key) + 1) + key[i + 1:]
+        key = key + (slice(None),) * (len(self.shape) - len(key))
+        out, squeeze = [], []
+        for k, n in zip(key, self.shape):
+            if isinstance(k, (int, np.integer)):
+                k = int(k) + (n if k < 0 else 0)
+                out.append((k, k + 1))
+                squeeze.append(True)
+            else:
+                a, b, st = k.indices(n)
+                if st != 1:
+                    raise IndexError("only unit-step slices are supported")
+                out.append((a, max(a, b)))
+                squeeze.append(False)
+        return out, squeeze
+
+    def _blocks(self, bounds):
+        """chunk indices touching the selection + (chunk slice, selection slice) per dimension"""
+        import itertools
+        per_dim = []
+        for (a, b), c in zip(bounds, self.chunks):
+            items = []
+            for ci in range(a // c, (b - 1) // c + 1 if b > a else a // c):
+                lo, hi = max(a, ci * c), min(b, (ci + 1) * c)
+                items.append((ci, slice(lo - ci * c, hi - ci * c), slice(lo - a, hi - a)))
+            per_dim.append(items)
+        return itertools.product(*per_dim)
+
+    def __getitem__(self, key):
+        bounds, squeeze = self._norm(key)
+        out = np.empty(tuple(b - a for a, b in bounds), dtype=self.dtype)
+        for combo in self._blocks(bounds):
+            chunk = self.read_chunk(tuple(c[0] for c in combo))
+            out[tuple(c[2] for c in combo)] = chunk[tuple(c[1] for c in combo)]
+        return out[tuple(0 if sq else slice(None) for sq in squeeze)]
+
+    def __setitem__(self, key, value):
+        bounds, squeeze = self._norm(key)
+        shape = tuple(b - a for a, b in bounds)
+        kept = [n for n, sq in zip(shape, squeeze) if not sq]
+        value = np.broadcast_to(np.asarray(value, dtype=self.dtype), kept).reshape(shape)
+        for combo in self._blocks(bounds):
+            idx = tuple(c[0] for c in combo)
+            csl = tuple(c[1] for c in combo)
+            whole = all(sl.start == 0 and sl.stop == c for sl, c in zip(csl, self.chunks))
+            chunk = np.empty(self.chunks, dtype=self.dtype) if whole else self.read_chunk(idx)
+            chunk[csl] = value[tuple(c[2] for c in combo)]
+            self.write_chunk(idx, chunk)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self[...], dtype=dtype)
+
+    def write_slab(self, z0, slab, pool=None):
+        """slab (n, Y, X) covering the chunk rows starting at z0 of an array chunked (1, Y, X) -- the reference's
+        output layout.  One file per slice straight from the slab's memory; with a ThreadPoolExecutor the writes are
+        submitted and the futures returned (file writes release the GIL)."""
+        if self.chunks[0] != 1 or tuple(self.chunks[1:]) != tuple(self.shape[1:]) or tuple(slab.shape[1:]) != tuple(self.shape[1:]):
+            raise ValueError("write_slab needs chunks (1, Y, X) and a slab of whole slices")
+        tail = (0,) * (len(self.shape) - 1)
+        if pool is None:
+            for i in range(slab.shape[0]):
+                self.write_chunk((z0 + i,) + tail, slab[i:i + 1])
+            return []
+        return [pool.submit(self.write_chunk, (z0 + i,) + tail, slab[i:i + 1]) for i in range(slab.shape[0])]
+
+
+class ZarrV2Group:
+    """A zarr v2 group directory: `create_dataset(name, shape=, dtype=, chunks=, overwrite=)` with the keywords the
+    reference passes, `group[name]` to open an array."""
+
+    def __init__(self, path, mode='a'):
+        self.path = path
+        marker = os.path.join(path, '.zgroup')
+        if mode == 'r' and not os.path.exists(marker):
+            raise FileNotFoundError(marker)
+        if not os.path.exists(marker):
+            os.makedirs(path, exist_ok=True)
+            with open(marker, 'w') as fh:
+                json.dump({'zarr_format': 2}, fh)
+
+    def create_dataset(self, name, shape, dtype, chunks=None, overwrite=False, compressor=None, fill_value=0):
+        path = os.path.join(self.path, name)
+        if os.path.exists(path):
+            if not overwrite:
+                raise FileExistsError(path)
+            shutil.rmtree(path)
+        os.makedirs(path)
+        shape = tuple(int(s) for s in shape)
+        chunks = shape if chunks is None else tuple(int(s if c is None else c) for s, c in zip(shape, chunks))
+        dt = np.dtype(dtype)
+        meta = {'chunks': list(chunks), 'compressor': None if compressor is None else {'id': 'zlib', 'level': int(compressor)},
+                'dtype': dt.str if dt.itemsize > 1 else '|' + dt.str[1:], 'fill_value': fill_value, 'filters': None,
+                'order': 'C', 'shape': list(shape), 'zarr_format': 2}
+        with open(os.path.join(path, '.zarray'), 'w') as fh:
+            json.dump(meta, fh, indent=4)
+        return ZarrV2Array(path, meta)
+
+    def __getitem__(self, name):
+        return ZarrV2Array(os.path.join(self.path, name))
+
+    def __contains__(self, name):
+        return os.path.exists(os.path.join(self.path, name, '.zarray'))
+
+
+def open_zarr(path, mode='a'):
+    """`zarr.open(path, mode=...)` for a v2 directory store: a group, or an array if `path` holds a .zarray"""
+    if os.path.exists(os.path.join(path, '.zarray')):
+        return ZarrV2Array(path)
+    return ZarrV2Group(path, mode)
+
+
+class SlabWriter:
+    """Asynchronous writer of labelled slabs into a (1, Y, X)-chunked zarr array: the device -> pinned-host copy of
+    pass k is handed over, its chunk files are written by a small thread pool while the GPU runs pass k + 1, and two
+    pinned buffers alternate so that a buffer is never overwritten while its files are being written."""
+
+    def __init__(self, array, z0, slab_shape, torch_dtype, threads=4, buffers=2):
+        import torch
+        self.array, self.z0 = array, int(z0)
+        self.pool = ThreadPoolExecutor(max_workers=threads)
+        self.bufs = [torch.empty(tuple(slab_shape), dtype=torch_dtype) for _ in range(buffers)]
+        if torch.cuda.is_available():
+            self.bufs = [b.pin_memory() for b in self.bufs]
+        self.pending = [[] for _ in range(buffers)]
+        self.turn = 0
+        self.np_dtype = array.dtype
+
+    def next_buffer(self):
+        """a pinned buffer that is safe to overwrite (its previous files are on disk)"""
+        i = self.turn
+        for f in self.pending[i]:
+            f.result()
+        self.pending[i] = []
+        return self.bufs[i]
+
+    def submit(self):
+        """the buffer handed out last is complete on the host: write its chunk files in the background"""
+        i = self.turn
+        self.pending[i] = self.array.write_slab(self.z0, self.bufs[i].numpy().view(self.np_dtype), self.pool)
+        self.turn = (i + 1) % len(self.bufs)
+
+    def drain(self):
+        for lst in self.pending:
+            for f in lst:
+                f.result()
+        self.pending = [[] for _ in self.bufs]
+
+    def close(self):
+        self.drain()
+        self.pool.shutdown()

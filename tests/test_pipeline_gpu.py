@@ -267,6 +267,14 @@ def test_trackers_and_chunked_fill():
                 arr = ChunkedArray(np.zeros(vol.shape, np.uint32), chunks)
                 zarr_fill_instances(arr, tr.instances, 4)
                 np.testing.assert_array_equal(arr.array, g[f'zf{j}_vol'], err_msg=str(chunks))
+                if j % 4 == 0:               # the same fill into an on-disk zarr v2 array (scripts/pdl_inference3d.py:228-233)
+                    import tempfile
+                    from empanada_amd.zarr_utils import ZarrV2Group, open_zarr
+                    with tempfile.TemporaryDirectory() as d:
+                        ds = ZarrV2Group(d + '/out.zarr').create_dataset('mito_pred', shape=vol.shape, dtype=np.uint32,
+                                                                         overwrite=True, chunks=chunks)
+                        zarr_fill_instances(ds, tr.instances, 4)
+                        np.testing.assert_array_equal(open_zarr(ds.path)[...], g[f'zf{j}_vol'], err_msg=str(chunks))
 
 
 def test_model_forward_matches_cpu_within_tolerance():

@@ -1,0 +1,87 @@
+"""CPU: the zarr v2 directory store written without the zarr package (empanada_amd/zarr_utils.py) -- the output
+container of scripts/pdl_inference3d.py:225-233.  Checked against the published v2 layout byte by byte (metadata keys,
+chunk file names, raw little-endian C-order chunk contents, padded edge chunks), plus round trips."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from empanada_amd.zarr_utils import SlabWriter, ZarrV2Array, ZarrV2Group, open_zarr
+
+
+def test_layout_matches_the_v2_spec(tmp_path):
+    root = str(tmp_path / 'vol.zarr')
+    g = ZarrV2Group(root)
+    assert json.load(open(os.path.join(root, '.zgroup'))) == {'zarr_format': 2}
+    a = g.create_dataset('mito_pred', shape=(3, 5, 6), dtype=np.uint32, overwrite=True, chunks=(1, None, None))
+    meta = json.load(open(os.path.join(a.path, '.zarray')))
+    assert meta == {'chunks': [1, 5, 6], 'compressor': None, 'dtype': '<u4', 'fill_value': 0, 'filters': None,
+                    'order': 'C', 'shape': [3, 5, 6], 'zarr_format': 2}
+    x = np.arange(90, dtype=np.uint32).reshape(3, 5, 6) * 70001
+    a[...] = x
+    assert sorted(os.listdir(a.path)) == ['.zarray', '0.0.0', '1.0.0', '2.0.0']
+    for z in range(3):
+        raw = open(os.path.join(a.path, f'{z}.0.0'), 'rb').read()
+        assert raw == x[z].astype('<u4').tobytes()
+    b = g.create_dataset('er_pred', shape=(3, 5, 6), dtype=np.uint8, chunks=(2, 4, 4), compressor=1)
+    meta = json.load(open(os.path.join(b.path, '.zarray')))
+    assert meta['dtype'] == '|u1' and meta['compressor'] == {'id': 'zlib', 'level': 1} and meta['chunks'] == [2, 4, 4]
+    y = (np.arange(90) % 251).astype(np.uint8).reshape(3, 5, 6)
+    b[...] = y
+    edge = np.frombuffer(zlib.decompress(open(os.path.join(b.path, '1.1.1'), 'rb').read()), dtype=np.uint8)
+    edge = edge.reshape(2, 4, 4)                                   # edge chunk: full chunk shape, padded
+    np.testing.assert_array_equal(edge[:1, :1, :2], y[2:, 4:, 4:])
+    assert (edge[1:] == 0).all() and (edge[:, 1:] == 0).all() and (edge[:, :, 2:] == 0).all()
+    with pytest.raises(FileExistsError):
+        g.create_dataset('er_pred', shape=(1, 1, 1), dtype=np.uint8)
+    assert 'er_pred' in g and 'nope' not in g
+
+
+def test_slicing_round_trips(tmp_path):
+    rng = np.random.default_rng(0)
+    g = ZarrV2Group(str(tmp_path / 'v.zarr'))
+    for chunks in [(1, None, None), (4, 3, 5), (7, 11, 13), (2, 11, 1)]:
+        a = g.create_dataset('a', shape=(7, 11, 13), dtype=np.uint32, chunks=chunks, overwrite=True)
+        ref = np.zeros((7, 11, 13), dtype=np.uint32)
+        assert (a[...] == 0).all()                                   # missing chunks read as fill_value
+        for _ in range(25):
+            lo = [int(rng.integers(0, n)) for n in ref.shape]
+            hi = [int(rng.integers(l + 1, n + 1)) for l, n in zip(lo, ref.shape)]
+            sl = tuple(slice(l, h) for l, h in zip(lo, hi))
+            val = rng.integers(0, 2 ** 32, size=ref[sl].shape, dtype=np.uint32)
+            a[sl] = val
+            ref[sl] = val
+            sl2 = tuple(slice(int(rng.integers(0, n)), None) for n in ref.shape)
+            np.testing.assert_array_equal(a[sl2], ref[sl2])
+        np.testing.assert_array_equal(np.asarray(open_zarr(a.path)), ref)
+        np.testing.assert_array_equal(a[3], ref[3])
+        np.testing.assert_array_equal(a[-1, 2:5], ref[-1, 2:5])
+        a[2] = 9
+        ref[2] = 9
+        np.testing.assert_array_equal(a[1:4], ref[1:4])
+
+
+def test_unsupported_codecs_fail_loudly(tmp_path):
+    p = tmp_path / 'x'
+    p.mkdir()
+    (p / '.zarray').write_text(json.dumps({'chunks': [1], 'compressor': {'id': 'blosc', 'cname': 'lz4'}, 'dtype': '<u4',
+                                           'fill_value': 0, 'filters': None, 'order': 'C', 'shape': [1],
+                                           'zarr_format': 2}))
+    with pytest.raises(KeyError, match='blosc'):
+        ZarrV2Array(str(p))
+
+
+def test_slab_writer_double_buffers(tmp_path):
+    torch = pytest.importorskip('torch')
+    g = ZarrV2Group(str(tmp_path / 'w.zarr'))
+    a = g.create_dataset('pred', shape=(10, 6, 8), dtype=np.uint32, chunks=(1, None, None))
+    w = SlabWriter(a, 4, (3, 6, 8), torch.int32, threads=2)
+    for k in range(5):
+        buf = w.next_buffer()
+        buf.copy_(torch.full((3, 6, 8), k + 1, dtype=torch.int32))
+        w.submit()
+    w.close()
+    out = a[...]
+    assert (out[4:7] == 5).all() and (out[:4] == 0).all() and (out[7:] == 0).all()
