@@ -5,7 +5,7 @@ import os
 
 import yaml
 
-__all__ = ['load_config', 'load_train_config', 'load_inference_config']
+__all__ = ['load_config', 'read_yaml', 'load_train_config', 'load_inference_config']
 
 
 def _merge(base, update):
@@ -15,6 +15,12 @@ def _merge(base, update):
         else:
             base[k] = v
     return base
+
+
+def read_yaml(url):
+    """config_loaders.py:10-17"""
+    with open(url, mode='r') as handle:
+        return yaml.load(handle, Loader=yaml.SafeLoader)
 
 
 def load_config(url):

@@ -12,7 +12,7 @@ import torch
 
 from . import _hip
 
-__all__ = ['DeviceVolume', 'normalize_constants', 'AXES']
+__all__ = ['DeviceVolume', 'VolumeDataset', 'normalize_constants', 'AXES']
 
 AXES = {'xy': 0, 'xz': 1, 'yz': 2}
 
@@ -73,3 +73,26 @@ class DeviceVolume:
         hi = self.n_slices(axis) if hi is None else hi
         for s in range(lo, hi, batch):
             yield s, self.batch(axis, s, min(hi, s + batch))
+
+
+class VolumeDataset:
+    """Map-style dataset over the slices of a volume along an axis, the reference's host-side reader
+    (empanada/data/volume_dataset.py:7-53): item = {'index', 'image', 'size'} with `tfs(image=...)['image']` applied.
+    `array` may be anything `array_utils.take` can slice (numpy, ZarrV2Array).  `scale` > 1 (power-of-two
+    down-sampling through cv2.resize in the reference) is not on the hot path and not supported."""
+
+    def __init__(self, array, axis=0, tfs=None, scale=1):
+        if scale != 1:
+            raise NotImplementedError("VolumeDataset: down-sampling (scale > 1) is outside the hot path")
+        self.array, self.axis, self.tfs, self.scale = array, axis, tfs, scale
+
+    def __len__(self):
+        return self.array.shape[self.axis]
+
+    def __getitem__(self, idx):
+        from .array_utils import take
+        image = np.asarray(take(self.array, idx, self.axis))
+        h, w = image.shape
+        if self.tfs is not None:
+            image = self.tfs(image=image)['image']
+        return {'index': idx, 'image': image, 'size': (h, w)}

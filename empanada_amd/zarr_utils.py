@@ -171,6 +171,7 @@ class ZarrV2Array:
         self.sep = meta.get('dimension_separator', '.')
         self.zlib_level = None if comp is None else int(comp.get('level', 1))
         self.nchunks = math.prod(math.ceil(s / c) for s, c in zip(self.shape, self.chunks))
+        self.ndim = len(self.shape)
 
     # -- chunk files
     def _chunk_path(self, idx):
