@@ -71,10 +71,11 @@ class PlaneTracks:
 
     def offsets(self):
         """CSR offsets (device int64, n_inst + 1) of the instances in the local run arrays"""
-        off = torch.empty((self.n_inst + 1,), dtype=torch.int64, device=self.ln.device)
-        _hip.call('emp_track_offsets', _hip._ptr(self.key) if self.n_runs else None, self.n_runs, self.n_inst,
+        top = self.inst_base + self.n_inst                       # keys carry inst_base + instance
+        off = torch.empty((top + 1,), dtype=torch.int64, device=self.ln.device)
+        _hip.call('emp_track_offsets', _hip._ptr(self.key) if self.n_runs else None, self.n_runs, top,
                   _hip._ptr(off), _hip.stream())
-        return off
+        return off[self.inst_base:]
 
     def trackers(self):
         """Reference-ordered InstanceTracker per class (tracker.py:102-121 result): D2H of the run arrays + the

@@ -132,3 +132,96 @@ def test_two_virtual_ranks_equal_single_rank(stack):
         parts.append(slab[:hi - lo])
     both = torch.cat([p.view(torch.int32) for p in parts], dim=0)
     assert torch.equal(both, single.view(torch.int32))
+
+
+# ------------------------------------------------------------------------------------------------ configs[2]: 512^3
+def test_orthoplane_512_cubed_properties_and_oracle_subvolume(tmp_path):
+    """BASELINE configs[2] at its full size through bench.py's own orthoplane path (three planes -> device-resident
+    trackers -> consensus on tables -> fill -> zarr), checked with size-independent properties:
+      * conservation: every consensus instance paints exactly the voxels its table says (minus what later instances
+        overwrite: none here, the planted objects are disjoint), ids are exactly the surviving ids;
+      * the planted ground truth is recovered (PQ against the planted labels);
+      * determinism: a second pass is bit-identical;
+      * encode -> write -> read: the zarr array read back equals the device volume;
+    and, on a 96^3 corner sub-volume (what the oracle finishes in seconds), the consensus volume equals the oracle's
+    bit for bit, ids included."""
+    import bench
+    from empanada_amd import synthetic as SY
+    from empanada_amd.evaluation import volume_pq
+    from empanada_amd.zarr_utils import SlabWriter, ZarrV2Group, open_zarr
+    from oracle import consensus as OC
+    from oracle import postprocess as OP
+    from oracle import rle_ops as OR
+    from oracle import rle_seg as OS
+    S2 = 512
+    truth = {}
+    stacks, heads, n_obj, _ = bench.build_inputs_ortho(S2, torch.device('cuda'), labels_out=truth)
+    ds = ZarrV2Group(str(tmp_path / 'o.zarr')).create_dataset('mito_pred', shape=(S2,) * 3, dtype=np.uint32,
+                                                                chunks=(1, None, None))
+    writer = SlabWriter(ds, 0, (S2,) * 3, torch.int32)
+    n_found, vol, zs = bench.postprocess_planes(heads, (S2,) * 3, writer, {})
+    writer.close()
+    assert zs == (0, S2) and n_found > 0.9 * n_obj
+    v = vol.view(torch.int32)
+    ids, counts = torch.unique(v, return_counts=True)
+    ids, counts = ids.cpu().numpy(), counts.cpu().numpy()
+    assert ids[0] == 0 and len(ids) - 1 == n_found
+    # second pass: identical, and its tables give the conservation check
+    from empanada_amd.inference import sharded
+    n2, vol2, _ = bench.postprocess_planes(heads, (S2,) * 3, None, {})
+    assert n2 == n_found and torch.equal(vol2.view(torch.int32), v)
+    planes, base = {}, 0
+    for axis in ('xy', 'xz', 'yz'):
+        h = heads[axis]
+        pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False, **bench.ENGINE)
+        planes[axis] = sharded.track_plane(pan, axis, (S2,) * 3, [1], [1], bench.ENGINE['label_divisor'],
+                                           inst_base=base, **bench.MATCH)
+        base += planes[axis].n_inst
+    cons, _, _ = sharded.consensus_volume(planes, (S2,) * 3, [1], [1], min_size=bench.FILTERS['min_size'],
+                                          min_span=bench.FILTERS['min_span'], **bench.CONSENSUS)
+    res = cons[1]
+    alive_ids = np.flatnonzero(res.alive) + 1
+    np.testing.assert_array_equal(ids[1:], alive_ids)
+    np.testing.assert_array_equal(counts[1:], res.areas[res.alive])
+    # a plane tracker's voxel count per instance equals the sum of its 3D run lengths (lift conservation)
+    for pt in planes.values():
+        off = pt.offsets().cpu().numpy()
+        cs = np.concatenate([[0], np.cumsum(pt.ln[:pt.n_runs].cpu().numpy())])
+        np.testing.assert_array_equal(cs[off[1:]] - cs[off[:-1]], pt.inst_area)
+    pq, n_gt, n_pred, n_match = volume_pq(truth['lab'].astype(np.uint32), v.cpu().numpy().astype(np.uint32))
+    assert pq > 0.9 and n_match >= 0.95 * n_gt
+    # zarr round trip
+    back = open_zarr(ds.path)
+    for z in (0, 1, S2 // 2, S2 - 1):
+        np.testing.assert_array_equal(back[z], v[z].cpu().numpy().astype(np.uint32))
+    del heads, vol, vol2, planes
+    torch.cuda.empty_cache()
+
+    # ---- corner sub-volume against the oracle
+    n = 96
+    shape = (n, n, n)
+    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321)
+    sub = {a: SY.planted_heads(lab, cls, a, seed=99) for a in ('xy', 'xz', 'yz')}
+    div, things = bench.ENGINE['label_divisor'], [1]
+    trackers = OS.create_axis_trackers(['xy', 'xz', 'yz'], [1], div, shape)
+    for axis in ('xy', 'xz', 'yz'):
+        sem, ctr, off = (sub[axis][k].numpy() for k in ('sem', 'ctr_hmp', 'offsets'))
+        pans = OP.engine3d_stack([sem[t:t + 1] for t in range(n)], [ctr[t:t + 1] for t in range(n)],
+                                 [off[t:t + 1] for t in range(n)], coarse_boundaries=False, render=True, **bench.ENGINE)
+        pans = [p.squeeze() for p in pans]
+        matchers = OS.create_matchers(things, div, 0.25, 0.25)
+        stack = OS.forward_matching(pans, matchers, [1], div, things)
+        for idx, rs in OS.backward_matching(stack, matchers, n):
+            OS.update_trackers(rs, idx, trackers[axis])
+        OS.finish_tracking(trackers[axis])
+        for tr in trackers[axis]:
+            OS.remove_small_objects(tr, bench.FILTERS['min_size'])
+            OS.remove_pancakes(tr, bench.FILTERS['min_span'])
+    con = OC.create_instance_consensus([t for a in ('xy', 'xz', 'yz') for t in trackers[a]], 2, 0.75, False)
+    OS.remove_small_objects(con, bench.FILTERS['min_size'])
+    OS.remove_pancakes(con, bench.FILTERS['min_span'])
+    exp = OR.numpy_fill_instances(np.zeros(shape, np.uint32), con.instances)
+    dev = {a: {k: t.cuda().contiguous() for k, t in sub[a].items()} for a in sub}
+    _, got, _ = bench.postprocess_planes(dev, shape, None, {})
+    assert exp.max() >= 3
+    np.testing.assert_array_equal(got.view(torch.int32).cpu().numpy().astype(np.uint32), exp)
