@@ -237,7 +237,12 @@ class Pipeline:
         nc = 1 if len(LABELS) == 1 else len(LABELS) + 1
         prob = torch.empty((hi - lo, nc, h, w), dtype=torch.float32, device=self.device)
         chk = torch.zeros((), dtype=torch.float64, device=self.device)
-        for s, x in dv.batches(axis, self.slices_per_call(h, w), lo, hi):
+        per = self.slices_per_call(h, w)
+        hp, wp = dv.padded_shape(axis)
+        for s in range(lo, hi, per):
+            e = min(hi, s + per)
+            buf = model.input_buffer((e - s, 1, hp, wp)) if model is self.graphed else None
+            x = dv.batch(axis, s, e, out=buf)        # straight into the graph's input: no device-to-device copy
             if self.dtype != torch.float32:
                 x = x.to(self.dtype)
             out = model(x.contiguous(memory_format=torch.channels_last))

@@ -81,6 +81,8 @@ SIGNATURES = {
     'emp_fill_table_u32': (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     'emp_scatter_yz_u32': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     'emp_fill_runs_u8': (_I, [_P, _L, _P, _P, _L, _c.c_uint8, _P]),
+    'emp_triplets_reduce_work_bytes': (_L, [_L]),
+    'emp_triplets_reduce': (_I, [_P, _L, _P, _L, _P, _P, _P]),
     'emp_track_work_elems': (_L, [_L]),
     'emp_track_lift': (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, _P]),
     'emp_track_lift_yz': (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _I, _L, _P, _P, _P]),
@@ -310,8 +312,22 @@ def overlap_next(t, label_divisor):
              _ptr(t.row_offsets), t.n_runs, t.D, t.H, t.W, int(label_divisor), _ptr(out), cap, _ptr(n), stream())
         cnt = int(n.item())
         if cnt <= cap:
-            return out[:cnt]
+            return reduce_triplets(out[:cnt])
         cap = cnt
+
+
+def reduce_triplets(trip):
+    """(n, 3) int32 (a, b, pixels) per run pair -> one row per (a, b) with the pixels summed, ascending (a, b)"""
+    n = int(trip.shape[0])
+    if n == 0:
+        return trip
+    dev = trip.device
+    wb = query('emp_triplets_reduce_work_bytes', n)
+    work = torch.empty((wb,), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 3), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    call('emp_triplets_reduce', _ptr(trip.contiguous()), n, _ptr(work), wb, _ptr(out), _ptr(cnt), stream())
+    return out[:int(cnt.item())]
 
 
 def sort_u64_i32(keys, vals, begin_bit=0, end_bit=64):

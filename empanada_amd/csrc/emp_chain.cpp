@@ -43,40 +43,35 @@ struct Chain {
     int64_t next_label;
     emp_lsap_fn lsap;
     int error = 0;
+    std::vector<int> row_nnz, col_nnz;             // scratch, reused over the slices
+    std::vector<double> iou;
+    std::vector<int64_t> rows, cols, arg;
+    std::vector<float> best;
 
-    // target / match instances, inter (nt x nm, row-major) -> relabelled (possibly merged) match instances
-    Inst match(const Inst &target, const Inst &m, const std::vector<int64_t> &inter, bool assign_new)
+    // target / match instances + their non-zero intersections as sparse entries (row i of target, column j of match,
+    // pixels; every (i, j) at most once, sorted by (i, j)) -> relabelled (possibly merged) match instances.
+    // The dense nt x nm matrices of the reference exist only where scipy needs one (the Hungarian step).
+    struct Entry { int64_t i, j, v; };
+    Inst match(const Inst &target, const Inst &m, const std::vector<Entry> &ent, bool assign_new)
     {
         const int64_t nt = (int64_t)target.size(), nm = (int64_t)m.size();
         if (nm == 0) return m;
         std::vector<int64_t> new_labels(nm, -1);
         std::vector<int64_t> rest;
         if (nt > 0) {
-            std::vector<int> row_nnz(nt, 0), col_nnz(nm, 0);
-            bool any = false, forced = true;
-            for (int64_t i = 0; i < nt; ++i)
-                for (int64_t j = 0; j < nm; ++j)
-                    if (inter[i * nm + j] != 0) {
-                        any = true;
-                        if (++row_nnz[i] > 1 || ++col_nnz[j] > 1) forced = false;
-                    }
-            std::vector<double> iou;
-            std::vector<float> ioa((size_t)nt * nm, 0.f);
-            for (int64_t i = 0; i < nt; ++i)
-                for (int64_t j = 0; j < nm; ++j) {
-                    const int64_t iv = inter[i * nm + j];
-                    if (iv != 0) ioa[i * nm + j] = (float)((double)iv / (double)m.areas[j]);
-                }
-            auto iou_at = [&](int64_t i, int64_t j) {
-                const int64_t iv = inter[i * nm + j];
-                return (double)iv / (double)(target.areas[i] + m.areas[j] - iv);
+            row_nnz.assign(nt, 0);
+            col_nnz.assign(nm, 0);
+            bool forced = true;
+            for (const Entry &e : ent)
+                if (++row_nnz[e.i] > 1 || ++col_nnz[e.j] > 1) forced = false;
+            auto iou_of = [&](const Entry &e) {
+                return (double)e.v / (double)(target.areas[e.i] + m.areas[e.j] - e.v);
             };
-            if (any && !forced) {
+            if (!ent.empty() && !forced) {
                 iou.assign((size_t)nt * nm, 0.0);
-                for (int64_t i = 0; i < nt; ++i)
-                    for (int64_t j = 0; j < nm; ++j)
-                        if (inter[i * nm + j] != 0) iou[i * nm + j] = iou_at(i, j);
-                std::vector<int64_t> rows(std::min(nt, nm)), cols(std::min(nt, nm));
+                for (const Entry &e : ent) iou[e.i * nm + e.j] = iou_of(e);
+                rows.resize(std::min(nt, nm));
+                cols.resize(std::min(nt, nm));
                 const int64_t k = lsap(iou.data(), nt, nm, rows.data(), cols.data());
                 if (k < 0) {
                     error = 2;
@@ -85,20 +80,22 @@ struct Chain {
                 for (int64_t q = 0; q < k; ++q)
                     if (iou[rows[q] * nm + cols[q]] >= iou_thr) new_labels[cols[q]] = target.labels[rows[q]];
             } else {
-                for (int64_t i = 0; i < nt; ++i)
-                    for (int64_t j = 0; j < nm; ++j)
-                        if (inter[i * nm + j] != 0 && iou_at(i, j) >= iou_thr) new_labels[j] = target.labels[i];
+                for (const Entry &e : ent)
+                    if (iou_of(e) >= iou_thr) new_labels[e.j] = target.labels[e.i];
+            }
+            // unmatched columns: first maximum of the fp32 IoA column (rows ascending; absent entries are 0)
+            best.assign(nm, 0.f);
+            arg.assign(nm, 0);
+            for (const Entry &e : ent) {                      // entries are sorted by row: strict > keeps the first
+                const float a = (float)((double)e.v / (double)m.areas[e.j]);
+                if (a > best[e.j]) {
+                    best[e.j] = a;
+                    arg[e.j] = e.i;
+                }
             }
             for (int64_t j = 0; j < nm; ++j) {
                 if (new_labels[j] >= 0) continue;
-                float best = ioa[j];
-                int64_t arg = 0;
-                for (int64_t i = 1; i < nt; ++i)
-                    if (ioa[i * nm + j] > best) {
-                        best = ioa[i * nm + j];
-                        arg = i;
-                    }
-                if (best >= ioa_thr) new_labels[j] = target.labels[arg];
+                if (best[j] >= ioa_thr) new_labels[j] = target.labels[arg[j]];
                 else rest.push_back(j);
             }
         } else {
@@ -191,26 +188,37 @@ int emp_chain_class(int64_t D, const int64_t *bounds, const int64_t *comp_label,
         ch.ioa_thr = (float)ioa_thr;
         ch.next_label = class_id * label_divisor + 1;
         ch.lsap = lsap;
-        std::vector<int64_t> rmap, cmap, inter;
+        std::vector<int64_t> rmap, cmap;
+        std::vector<Chain::Entry> ent;
         auto inter_of = [&](int64_t t, const Inst &rows, const Inst &cols, bool transposed) {
-            // rows live in slice t (+1 if transposed), cols in the other slice of the pair (t, t+1)
+            // rows live in slice t (+1 if transposed), cols in the other slice of the pair (t, t+1); component
+            // overlaps are summed per (row instance, column instance)
             const int64_t n0 = bounds[t + 1] - bounds[t], n1 = bounds[t + 2] - bounds[t + 1];
             comp_to_inst(rows, transposed ? n1 : n0, rmap);
             comp_to_inst(cols, transposed ? n0 : n1, cmap);
-            inter.assign(rows.size() * cols.size(), 0);
+            ent.clear();
             for (int64_t q = tb_bounds[t]; q < tb_bounds[t + 1]; ++q) {
                 const int64_t a = transposed ? pb[q] : pa[q], b = transposed ? pa[q] : pb[q];
                 const int64_t ri = rmap[a], ci = cmap[b];
-                if (ri >= 0 && ci >= 0) inter[ri * (int64_t)cols.size() + ci] += tv[q];
+                if (ri >= 0 && ci >= 0 && tv[q] != 0) ent.push_back({ri, ci, tv[q]});
             }
+            std::sort(ent.begin(), ent.end(), [](const Chain::Entry &x, const Chain::Entry &y) {
+                return x.i != y.i ? x.i < y.i : x.j < y.j;
+            });
+            size_t w = 0;
+            for (size_t q = 0; q < ent.size(); ++q) {
+                if (w && ent[w - 1].i == ent[q].i && ent[w - 1].j == ent[q].j) ent[w - 1].v += ent[q].v;
+                else ent[w++] = ent[q];
+            }
+            ent.resize(w);
         };
         std::vector<Inst> fwd(D);
         fwd[0] = slices[0];
         if (fwd[0].size()) ch.next_label = *std::max_element(fwd[0].labels.begin(), fwd[0].labels.end()) + 1;
         for (int64_t t = 1; t < D; ++t) {
             if (fwd[t - 1].size() && slices[t].size()) inter_of(t - 1, fwd[t - 1], slices[t], false);
-            else inter.assign(fwd[t - 1].size() * slices[t].size(), 0);
-            fwd[t] = ch.match(fwd[t - 1], slices[t], inter, true);
+            else ent.clear();
+            fwd[t] = ch.match(fwd[t - 1], slices[t], ent, true);
             if (ch.error) return ch.error;
         }
         result.resize(D);
@@ -219,8 +227,8 @@ int emp_chain_class(int64_t D, const int64_t *bounds, const int64_t *comp_label,
             ch.next_label = *std::max_element(result[D - 1].labels.begin(), result[D - 1].labels.end()) + 1;
         for (int64_t t = D - 2; t >= 0; --t) {
             if (result[t + 1].size() && fwd[t].size()) inter_of(t, result[t + 1], fwd[t], true);
-            else inter.assign(result[t + 1].size() * fwd[t].size(), 0);
-            result[t] = ch.match(result[t + 1], fwd[t], inter, false);
+            else ent.clear();
+            result[t] = ch.match(result[t + 1], fwd[t], ent, false);
             if (ch.error) return ch.error;
         }
     } else {

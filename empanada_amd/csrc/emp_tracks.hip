@@ -353,3 +353,95 @@ extern "C" int emp_track_clip(const uint64_t *key, const int64_t *len, int64_t n
         EMP_FAIL(EMP_ELAUNCH, "track_clip: count copy");
     return EMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------ overlap triplets
+// emp_runs_overlap_next emits one (comp_a, comp_b, pixels) triplet per overlapping RUN pair (~20 per component pair at
+// 1024^2); the chain wants one per COMPONENT pair.  Sort by (a, b) and sum the equal keys on the device, so that the
+// host receives and walks O(#component pairs) entries instead of O(#run pairs).
+__global__ void trip_keys_kernel(const int32_t *__restrict__ trip, int64_t n, uint64_t *__restrict__ keys,
+                                 int32_t *__restrict__ vals)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        keys[i] = ((uint64_t)(uint32_t)trip[3 * i] << 32) | (uint64_t)(uint32_t)trip[3 * i + 1];
+        vals[i] = trip[3 * i + 2];
+    }
+}
+
+__global__ void trip_heads_kernel(const uint64_t *__restrict__ keys, int64_t n, int32_t *__restrict__ head)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        head[i] = (i == 0 || keys[i - 1] != keys[i]) ? 1 : 0;
+}
+
+__global__ void trip_emit_kernel(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, int64_t n,
+                                 const int32_t *__restrict__ head, const int32_t *__restrict__ pos,
+                                 int32_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!head[i]) continue;
+        int32_t total = vals[i];
+        for (int64_t j = i + 1; j < n && !head[j]; ++j) total += vals[j];
+        const int64_t o = pos[i];
+        out[3 * o] = (int32_t)(keys[i] >> 32);
+        out[3 * o + 1] = (int32_t)(keys[i] & 0xffffffffULL);
+        out[3 * o + 2] = total;
+    }
+}
+
+struct TripWork {
+    int64_t keys_in, keys_out, vals_in, vals_out, head, pos, scantmp, cub, cub_bytes, total;
+};
+static TripWork trip_layout(int64_t n)
+{
+    TripWork L;
+    if (n < 1) n = 1;
+    int64_t o = 0;
+    L.keys_in = o; o += trk_align(n * 8);
+    L.keys_out = o; o += trk_align(n * 8);
+    L.vals_in = o; o += trk_align(n * 4);
+    L.vals_out = o; o += trk_align(n * 4);
+    L.head = o; o += trk_align(n * 4);
+    L.pos = o; o += trk_align((n + 1) * 4);
+    L.scantmp = o; o += trk_align(emp_scan_tmp_elems(n) * 4);
+    L.cub = o;
+    L.cub_bytes = emp_sort_work_bytes(n);
+    o += L.cub_bytes;
+    L.total = o;
+    return L;
+}
+extern "C" int64_t emp_triplets_reduce_work_bytes(int64_t n) { return trip_layout(n).total; }
+
+extern "C" int emp_triplets_reduce(const int32_t *trip, int64_t n, void *work, int64_t work_bytes, int32_t *out,
+                                   int32_t *n_out, void *stream)
+{
+    EMP_REQUIRE(n >= 0 && n < (1LL << 31) && n_out, "triplets_reduce: bad arguments");
+    hipStream_t st = emp_stream(stream);
+    if (n == 0) {
+        if (hipMemsetAsync(n_out, 0, sizeof(int32_t), st) != hipSuccess) EMP_FAIL(EMP_ELAUNCH, "triplets_reduce: memset");
+        return EMP_OK;
+    }
+    EMP_REQUIRE(trip && work && out, "triplets_reduce: null pointer");
+    TripWork L = trip_layout(n);
+    EMP_REQUIRE(work_bytes >= L.total, "triplets_reduce: workspace too small");
+    char *w = reinterpret_cast<char *>(work);
+    uint64_t *keys_in = reinterpret_cast<uint64_t *>(w + L.keys_in);
+    uint64_t *keys_out = reinterpret_cast<uint64_t *>(w + L.keys_out);
+    int32_t *vals_in = reinterpret_cast<int32_t *>(w + L.vals_in);
+    int32_t *vals_out = reinterpret_cast<int32_t *>(w + L.vals_out);
+    int32_t *head = reinterpret_cast<int32_t *>(w + L.head);
+    int32_t *pos = reinterpret_cast<int32_t *>(w + L.pos);
+    int32_t *scantmp = reinterpret_cast<int32_t *>(w + L.scantmp);
+    int grid = emp_grid(n, 256, 4096);
+    hipLaunchKernelGGL(trip_keys_kernel, dim3(grid), dim3(256), 0, st, trip, n, keys_in, vals_in);
+    EMP_CHECK_LAUNCH("emp_triplets_reduce(keys)");
+    int rc = emp_sort_u64_i32(keys_in, keys_out, vals_in, vals_out, n, 0, 64, w + L.cub, L.cub_bytes, stream);
+    if (rc != EMP_OK) return rc;
+    hipLaunchKernelGGL(trip_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, n, head);
+    rc = emp_exclusive_scan_i32(head, n, pos, scantmp, stream);
+    if (rc != EMP_OK) return rc;
+    hipLaunchKernelGGL(trip_emit_kernel, dim3(grid), dim3(256), 0, st, keys_out, vals_out, n, head, pos, out);
+    EMP_CHECK_LAUNCH("emp_triplets_reduce(emit)");
+    if (hipMemcpyAsync(n_out, pos + n, sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        EMP_FAIL(EMP_ELAUNCH, "triplets_reduce: count copy");
+    return EMP_OK;
+}

@@ -56,15 +56,18 @@ class DeviceVolume:
         rest = [i for i in range(3) if i != d]
         return st[d], st[rest[0]], st[rest[1]]
 
-    def batch(self, axis, lo, hi):
-        """slices [lo, hi) of the plane -> (hi-lo, 1, hp, wp) fp32 (memory is NCHW == NHWC for one channel)"""
+    def batch(self, axis, lo, hi, out=None):
+        """slices [lo, hi) of the plane -> (hi-lo, 1, hp, wp) fp32 (memory is NCHW == NHWC for one channel); `out`:
+        a contiguous tensor of that shape to fill instead of a new one (e.g. a HIP graph's static input)"""
         _hip.require_gpu()
         n = hi - lo
         assert 0 <= lo <= hi <= self.n_slices(axis)
         h, w = self.plane_shape(axis)
         hp, wp = self.padded_shape(axis)
         ss, sr, sc = self._strides(axis)
-        out = torch.empty((n, 1, hp, wp), dtype=torch.float32, device=self.vol.device)
+        if out is None:
+            out = torch.empty((n, 1, hp, wp), dtype=torch.float32, device=self.vol.device)
+        assert tuple(out.shape) == (n, 1, hp, wp) and out.dtype == torch.float32 and out.is_contiguous()
         _hip.call('emp_slices_to_input', self.vol.data_ptr() + lo * ss, ss, sr, sc, n, h, w, hp, wp, self.mean255,
                   self.inv_std255, out.data_ptr(), _hip.stream(), alg_bytes=n * h * w + 4 * out.numel())
         return out

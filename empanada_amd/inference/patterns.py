@@ -371,9 +371,10 @@ def _lsap_callback(iou_ptr, n_rows, n_cols, rows_out, cols_out):
     try:
         iou = np.ctypeslib.as_array(iou_ptr, shape=(n_rows, n_cols))
         rows, cols = linear_sum_assignment(iou, maximize=True)
-        for i in range(len(rows)):
-            rows_out[i] = int(rows[i])
-            cols_out[i] = int(cols[i])
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        ctypes.memmove(rows_out, rows.ctypes.data, rows.nbytes)
+        ctypes.memmove(cols_out, cols.ctypes.data, cols.nbytes)
         return len(rows)
     except Exception:                        # never unwind through the C frame
         return -1

@@ -402,6 +402,15 @@ int emp_scatter_yz_u32(uint32_t *vol, int Z, int Y, int X, const int32_t *r_star
                        const int32_t *r_comp, const int32_t *c_slice, const uint32_t *value,
                        int64_t n_runs, void *stream);
 
+/* ---- M2 (cont.): one triplet per COMPONENT pair -------------------------------------------------------------
+ * emp_runs_overlap_next emits one (comp_a, comp_b, pixels) triplet per overlapping run pair; the matcher needs the
+ * intersection of two instances (rle_intersection, array_utils.py:371-403), i.e. the sum over all run pairs of the two
+ * components.  emp_triplets_reduce sorts the triplets by (a, b) and sums equal pairs on the device: `out` (<= n
+ * triplets, ascending (a, b)), n_out device int32.  work: emp_triplets_reduce_work_bytes(n) bytes.               */
+int64_t emp_triplets_reduce_work_bytes(int64_t n);
+int emp_triplets_reduce(const int32_t *triplets, int64_t n, void *work, int64_t work_bytes, int32_t *out,
+                        int32_t *n_out, void *stream);
+
 /* ---- T1 on the device: run table of a plane's slices -> per-instance 3D runs sorted by (instance, start) ------
  * replaces InstanceTracker.update / finish        empanada/inference/tracker.py:61-123
  *          to_coords3d                             empanada/inference/tracker.py:25-38

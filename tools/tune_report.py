@@ -8,7 +8,9 @@ from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
 
 torch.backends.cudnn.benchmark = True
 model = prepare_for_inference(synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)), 'cuda')
-x = torch.rand(32, 1, 512, 512, device='cuda').contiguous(memory_format=torch.channels_last)
+import sys
+B, S = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 512)
+x = torch.rand(B, 1, S, S, device="cuda").contiguous(memory_format=torch.channels_last)
 rep = tune_fused_convs(model, x, reps=10)
 mods = dict(model.named_modules())
 rows = []
