@@ -320,9 +320,16 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
             }
         };
         const int swz_rd = (BK == 16) ? ((r >> 2) & 3) : ((r >> 1) & 7);
+        // Vector-memory operations in flight in this loop, in issue order (vmcnt retires in order):
+        //   [RESPF only] the NRE float4 residual prefetches issued before this point (compiler-tracked loads into
+        //   VGPRs; they are OLDER than every LDS-direct load, so any wait that lets at most NL younger operations
+        //   stay pending has also retired them -- and the compiler inserts its own wait before their first use in the
+        //   epilogue), then NL untracked LDS-direct loads per issued slab.  No stores and no atomics are issued before
+        //   the K loop ends (the PROJ atomics and all output stores live in the epilogue, after the final barrier).
+        //   cg_wait_vm<NL>: everything but the youngest slab's NL loads has landed; cg_wait_vm<0>: everything has.
         issue_slab(0);
         if (NBUF == 3 && S > 1) issue_slab(1);
-        if (NBUF == 3 && S > 1) cg_wait_vm<NL>(); else cg_wait_vm<0>();
+        if (NBUF == 3 && S > 1) cg_wait_vm<NL>(); else cg_wait_vm<0>();      // slab 0 landed (slab 1 may be pending)
         __builtin_amdgcn_s_barrier();
         for (int s = 0; s < S; ++s) {
             const int ring = s % NBUF;

@@ -60,6 +60,13 @@ def _bn_affine(bn):
     return scale, shift
 
 
+def _no_late_weights(state_dict, prefix, *args):
+    """The inference stand-ins fold their weights at construction (BatchNorm -> scale / shift, filters permuted or
+    Winograd-transformed): loading a state dict into a prepared model would leave those stale.  Fail loudly."""
+    raise RuntimeError("load_state_dict after prepare_for_inference: load the weights into the plain model first "
+                       f"(module {prefix.rstrip('.')!r} holds folded copies)")
+
+
 class DepthwiseConvNHWC(nn.Module):
     """Inference-only stand-in for Conv2d(C, C, k, padding=k//2, groups=C) on NHWC fp32 activations:
     emp_dwconv_nhwc (one HBM pass) instead of MIOpen's grouped-convolution kernel."""
@@ -97,6 +104,7 @@ class FusedBNAct(nn.Module):
         self.register_buffer('scale', scale, persistent=False)
         self.register_buffer('shift', shift, persistent=False)
         self.relu = relu
+        self._register_load_state_dict_pre_hook(_no_late_weights)
 
     def forward(self, x, residual=None, out=None):
         from .. import _hip

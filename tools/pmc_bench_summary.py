@@ -16,7 +16,7 @@ def load(d, counter):
         gy[r['Dispatch_Id']] = (int(r['Grid_Size_Y']), int(r['Start_Timestamp']))
     rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
-    marks = [i for i, r in enumerate(rows) if 'fill_table_kernel' in r['Kernel_Name']]
+    marks = [i for i, r in enumerate(rows) if 'fill_table_kernel' in r['Kernel_Name'] or 'fill_u32_kernel<1>' in r['Kernel_Name']]
     rows = rows[marks[0] + 1:] if len(marks) > 1 else rows          # after the warm-up pass
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in rows:
@@ -33,7 +33,7 @@ def load(d, counter):
 def main():
     fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
     mine = ('conv_igemm', 'wino_', 'wino3_', 'wino4_', 'pointwise_out', 'bn_relu_maxpool', 'slices_to_input', 'dwconv', 'bn_act', 'upsample_', 'median', 'find_centers', 'group_pixels', 'fuse_',
-            'row_runs', 'label_', 'overlap_next', 'fill_table')
+            'row_runs', 'label_', 'overlap_next', 'fill_table', 'fill_u32', 'trk_', 'trip_', 'vote_', 'pair_inter', 'box_pairs')
     print("# rocprofv3 PMC passes over bench.py (timed pass only): HBM traffic per launch\n")
     print("traffic = 2 x FETCH_SIZE + WRITE_SIZE (KiB), separate passes\n")
     print("| kernel | launches | FETCH_SIZE KiB / launch | WRITE_SIZE KiB / launch | traffic MB / launch |\n|---|---|---|---|---|")
