@@ -62,11 +62,12 @@ ALG_BYTES = {
 # on known byte counts), collected OFFLINE with the tuned implementation choices replayed: --pmc cannot run inside this
 # script.  The JSON line labels the figure `traffic_source: offline PMC`.
 PMC_TRAFFIC_RATIO = {
-    'emp_conv_bn_act_nhwc': 1.18, 'emp_bn_act_nhwc': 1.0, 'emp_dwconv_nhwc': 1.06, 'emp_upsample_bilinear': 1.2,
+    'emp_conv_bn_act_nhwc': 1.17, 'emp_bn_act_nhwc': 1.0, 'emp_dwconv_nhwc': 1.06, 'emp_upsample_bilinear': 1.2,
     'emp_median_harden_stack': 1.0, 'emp_find_centers': 1.14, 'emp_group_pixels': 1.26, 'emp_fuse_apply': 1.0,
     'emp_runs_count': 1.0, 'emp_runs_extract': 1.04,
 }
-PMC_SOURCE = 'offline PMC ratio x algorithmic bytes (profiles/r1_pmc_bench_dense.md, r1_pmc_postproc_256x512x512.md)'
+PMC_SOURCE = ('offline PMC ratio x algorithmic bytes (profiles/r2_pmc_bench_ortho512.md: same pixels per launch as this '
+              'workload; r1_pmc_postproc_256x512x512.md for the per-voxel kernels)')
 DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 'emp_conv_bn_act_nhwc',
                  'emp_conv_bn_act_proj_nhwc', 'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
                  'emp_wino_output_transform', 'emp_wino4_input_transform', 'emp_wino4_output_transform',
