@@ -219,6 +219,21 @@ class Pipeline:
         if save:
             json.dump({k: v[0] for k, v in rep.items()}, open(save, 'w'), indent=1)
 
+    def replays_next_forward(self):
+        """True if the next forward() call replays captured graphs (cheap to queue far ahead)"""
+        return self.graphed is not None and self.dtype == torch.float32 and self.dense_profile_left == 0
+
+    def adopt_choices_of_rank0(self):
+        """the tuner's timings differ slightly from GPU to GPU; all ranks take rank 0's choice per call site so that a
+        slice's logits do not depend on the rank that computed it"""
+        import torch.distributed as dist
+        from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
+        sites = [(n, m) for n, m in self.model.named_modules() if isinstance(m, FusedConvBNAct)]
+        box = [{n: m.impl for n, m in sites}]
+        dist.broadcast_object_list(box, src=0)
+        for n, m in sites:
+            m.impl = box[0].get(n, m.impl)
+
     @torch.no_grad()
     def forward(self, dv, axis='xy', lo=0, hi=None):
         """slices [lo, hi) of one plane of the resident uint8 volume (empanada_amd.data.DeviceVolume: strided
@@ -380,45 +395,58 @@ def postprocess_planes(heads, shape3d, writer, stages, between=None):
 
 
 def orthoplane_step(pipe, stacks, heads, shape3d, writer, stages, first=None, prefetch_next=False):
-    """One pass.  Two HIP streams: the forward of plane p+1 is queued (default stream) as soon as the device tables of
-    plane p are on the host; the host half of plane p and its device work run on the post-processing stream meanwhile.
-    With prefetch_next the xy forward of the NEXT pass is queued the same way behind the yz tables, so that the tail
-    (yz tracking, consensus, fill, D2H) runs under it; the caller hands the returned (checksum, event) back as `first`."""
+    """One pass.  Two HIP streams: forwards on the default stream, everything downstream of a plane's forward (pixel
+    kernels, tables, chain, lift; after the third plane consensus, fill, D2H, zarr write) on the post-processing stream
+    behind that forward's event.
+    When the forwards replay as HIP graphs (a dozen launches per plane) all of this pass's remaining forwards -- and,
+    with prefetch_next, the xy forward of the NEXT pass -- are queued up front: the GPU never waits for the host, which
+    matters most when the slices are sharded over several ranks and a plane's forward is as short as its host work.
+    Un-captured forwards (~11 000 launches per plane, more than the HIP queue holds) are queued one plane ahead instead:
+    plane p+1 as soon as the device tables of plane p are on the host.  The caller hands the returned
+    (checksum, event) back as `first`."""
     post = pipe.post_stream
     planes = ('xy', 'xz', 'yz')
-    state = {'chk': 0, 'next': None}
+    state = {'next': None}
+    ev, chk = {}, {}
+
+    def launch(axis, key=None):
+        key = key or axis
+        with torch.cuda.stream(torch.cuda.default_stream()):
+            _, chk[key] = pipe.forward(*stacks[axis])
+            ev[key] = torch.cuda.Event()
+            ev[key].record()
+
     if first is None:
-        _, c = pipe.forward(*stacks['xy'])
-        ev = torch.cuda.Event()
-        ev.record()
+        launch('xy')
     else:
-        c, ev = first
-    state['chk'] = c
-    state['ev'] = ev
+        chk['xy'], ev['xy'] = first
+    ahead = pipe.replays_next_forward()
+    if ahead:
+        launch('xz')
+        launch('yz')
+        if prefetch_next:
+            launch('xy', 'next')
 
     def between(i):
-        with torch.cuda.stream(torch.cuda.default_stream()):
-            if i + 1 < len(planes):
-                _, c = pipe.forward(*stacks[planes[i + 1]])
-                state['chk'] = state['chk'] + c
-                e = torch.cuda.Event()
-                e.record()
-                state['ev'] = e
-            elif prefetch_next:
-                _, c2 = pipe.forward(*stacks['xy'])
-                e2 = torch.cuda.Event()
-                e2.record()
-                state['next'] = (c2, e2)
+        if ahead:
+            return
+        if i + 1 < len(planes):
+            launch(planes[i + 1])
+        elif prefetch_next:
+            launch('xy', 'next')
 
     class _Heads(dict):                              # heads[axis] access = "plane `axis` starts": wait for its forward
         def __getitem__(self, axis):
-            post.wait_event(state['ev'])
+            assert axis in ev, f'forward of plane {axis} was never queued'
+            post.wait_event(ev[axis])
             return dict.__getitem__(self, axis)
 
     with torch.cuda.stream(post):
         n_found, _, _ = postprocess_planes(_Heads(heads), shape3d, writer, stages, between)
     torch.cuda.current_stream().wait_stream(post)
-    return state['chk'], n_found, state['next']
+    if 'next' in ev:
+        state['next'] = (chk['next'], ev['next'])
+    return chk['xy'] + chk['xz'] + chk['yz'], n_found, state['next']
 
 
 def cpu_baseline_ortho(args, n, cores):
@@ -492,6 +520,8 @@ def main_orthoplane(args, device, rank, world):
     pipe = Pipeline(args, device)
     if not args.no_tune:
         pipe.tune(S, args.save_tune, args.load_tune)
+        if world > 1:
+            pipe.adopt_choices_of_rank0()            # every rank runs the same kernels: slice-independent numerics
     shape3d = (S, S, S)
     from empanada_amd.inference.sharded import shard_bounds
     from empanada_amd.zarr_utils import SlabWriter, ZarrV2Group, open_zarr
