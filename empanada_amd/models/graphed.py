@@ -43,7 +43,9 @@ class GraphedForward(torch.nn.Module):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: HIP calls of OTHER threads (the RCCL watchdog's event queries in a multi-rank job, a writer
+        # pool) must not invalidate the capture running on this thread
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             static_out = self.model(static_in, *args, **kwargs)
         return graph, static_in, static_out
 
