@@ -133,3 +133,104 @@ def test_rccl_entry_points_world1():
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+class _ListQueue:
+    def __init__(self):
+        self.items = []
+
+    def put(self, item):
+        self.items.append(item)
+
+    def get(self):
+        return self.items.pop(0)
+
+
+class _Sink:
+    sent = None
+
+    def send(self, obj):
+        self.sent = obj
+
+    def close(self):
+        pass
+
+
+def _worker_multigpu(rank, world, port, case, q):
+    """the loop of scripts/inference3d_multigpu.py:351-378 with this package's names: strided slices per rank
+    (DistributedEvalSampler), MultiGPUInferenceEngine.get_instance_cells, patterns.all_gather of sem and cells after
+    every slice, rank 0 feeding the queue that forward_multigpu consumes"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from empanada_amd.inference import engines as EN
+        from empanada_amd.inference import patterns as PA
+        from empanada_amd.sampler import DistributedEvalSampler
+        g = load_golden('forward_multigpu')
+        C, ks, seed, n_out = (int(x) for x in g[f'c{case}_par'])
+        nthing = 1 if C == 1 else C - 1
+        lab, cls = SY.planted_labels((9, 56, 64), fill=0.25, rmin=4, rmax=9, seed=seed, n_classes=nthing)
+        heads = SY.planted_heads(lab, cls, 'xy', n_classes=nthing, seed=seed)
+        labels = [1] if C == 1 else [1, 2]
+        eng = EN.MultiGPUInferenceEngine(torch.nn.Identity(), thing_list=[1], label_divisor=1000, nms_kernel=7,
+                                         nms_threshold=0.1, confidence_thr=0.5, coarse_boundaries=False)
+        queue = _ListQueue()
+        n = lab.shape[0]
+        mine = list(DistributedEvalSampler(range(n), num_replicas=world, rank=rank))
+        rounds = -(-n // world)
+        for k in range(rounds):
+            z = mine[k] if k < len(mine) else mine[-1]               # ranks without a slice in the last round repeat one
+            sem = heads['sem'][z:z + 1].cuda()
+            cells = eng.get_instance_cells(heads['ctr_hmp'][z:z + 1].cuda(), heads['offsets'][z:z + 1].cuda())
+            sems = PA.all_gather(sem.cpu())                              # gloo moves host tensors
+            cells_all = PA.all_gather(cells.float().cpu())
+            if rank == 0:
+                for r in range(world):
+                    if k * world + r < n:                                # global order restored: k * world + r
+                        queue.put((sems[r].cuda(), cells_all[r].cuda()))
+        if rank == 0:
+            queue.put(('finish', 'finish'))
+            sink = _Sink()
+            PA.forward_multigpu(PA.create_matchers([1], 1000, 0.25, 0.25), queue, [], sink, 0.5, ks, labels, 1000, [1],
+                                16, 0)
+            stack = sink.sent[0]
+            out = [{c: {k2: (v['box'], np.asarray(v['starts']), np.asarray(v['runs'])) for k2, v in rs[c].items()}
+                    for c in labels} for rs in stack]
+            q.put((rank, out))
+        else:
+            q.put((rank, None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case', [0, 2])
+def test_multigpu_script_flow_over_gloo(case):
+    """two ranks, strided slices, all_gather after every slice, forward_multigpu on rank 0: the rle_stack equals the one
+    the reference's forward_multigpu produced from the same slices in order (tests/golden/forward_multigpu.npz)"""
+    from conftest import unpack_rle_seg
+    g = load_golden('forward_multigpu')
+    C, ks, seed, n_out = (int(x) for x in g[f'c{case}_par'])
+    labels = [1] if C == 1 else [1, 2]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_multigpu, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    stack = got[0]
+    assert got[1] is None and len(stack) == n_out
+    for z, rs in enumerate(stack):
+        exp = unpack_rle_seg(g, f'c{case}_z{z}')
+        for c in labels:
+            e = exp.get(c, {})
+            assert list(rs[c].keys()) == list(e.keys())
+            for k, (box, st, rn) in rs[c].items():
+                assert tuple(int(b) for b in box) == tuple(e[k]['box'])
+                np.testing.assert_array_equal(st, e[k]['starts'])
+                np.testing.assert_array_equal(rn, e[k]['runs'])
