@@ -355,16 +355,19 @@ def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None):
 
 
 # ----------------------------------------------------------------------------------------------- orthoplane
-def postprocess_planes(heads, shape3d, writer, stages, between=None):
+def postprocess_planes(heads, shape3d, writer, stages, between=None, before=None):
     """The part of a pass that follows the forwards, for all three planes (heads[axis] = the rank's block of head
     tensors): per plane pixels -> tables -> chain (replicated on every rank) -> device-resident trackers, then filters
     -> consensus -> filters -> fill of the rank's z-slab -> pinned host memory -> zarr chunk files.  `between(i)` is called once plane
-    i's device tables are on the host (the driver queues the next forward there).
+    i's device tables are on the host (the driver queues the next forward there), `before(axis)` right before plane
+    `axis` is touched (the driver makes the post-processing stream wait for that plane's forward there).
     Returns (#consensus instances, the rank's slab of the labelled volume on the device, (z0, z1))."""
     from empanada_amd.inference import sharded
     planes, base = {}, 0
     for i, axis in enumerate(('xy', 'xz', 'yz')):
         t0 = time.perf_counter()
+        if before is not None:
+            before(axis)
         h = heads[axis]
         pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False, **ENGINE)
         table, host = sharded.sharded_tables(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'])
@@ -435,14 +438,12 @@ def orthoplane_step(pipe, stacks, heads, shape3d, writer, stages, first=None, pr
         elif prefetch_next:
             launch('xy', 'next')
 
-    class _Heads(dict):                              # heads[axis] access = "plane `axis` starts": wait for its forward
-        def __getitem__(self, axis):
-            assert axis in ev, f'forward of plane {axis} was never queued'
-            post.wait_event(ev[axis])
-            return dict.__getitem__(self, axis)
+    def before(axis):                                # plane `axis` starts: its forward must have finished
+        assert axis in ev, f'forward of plane {axis} was never queued'
+        post.wait_event(ev[axis])
 
     with torch.cuda.stream(post):
-        n_found, _, _ = postprocess_planes(_Heads(heads), shape3d, writer, stages, between)
+        n_found, _, _ = postprocess_planes(heads, shape3d, writer, stages, between, before)
     torch.cuda.current_stream().wait_stream(post)
     if 'next' in ev:
         state['next'] = (chk['next'], ev['next'])

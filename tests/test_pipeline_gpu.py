@@ -644,3 +644,24 @@ def test_logits_to_prob_gpu_vs_cpu_at_the_threshold():
     gpu = logits_to_prob(x.cuda()).cpu()
     assert (gpu - cpu).abs().max().item() <= 5e-7
     assert int((gpu.argmax(dim=1) != cpu.argmax(dim=1)).sum()) == 0
+
+
+def test_forward_is_deterministic_from_run_to_run():
+    """the prepared model gives bit-identical heads on repeated calls, with the library convolutions and with the
+    hand-written kernels forced on: the one source of run-to-run differences found (a split-K library GEMM with atomic
+    accumulation in the ASPP image-pooling branch) runs on the fused conv kernel"""
+    from empanada_amd.models import PanopticDeepLab, prepare_for_inference, synthesize_weights
+    from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
+    m = prepare_for_inference(synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)), 'cuda')
+    x = torch.randn(4, 1, 256, 256, device='cuda').contiguous(memory_format=torch.channels_last)
+    for force in (None, 'direct'):
+        if force:
+            for mod in m.modules():
+                if isinstance(mod, FusedConvBNAct) and force in mod.candidates(False):
+                    mod.impl = force
+        with torch.no_grad():
+            a = {k: v.clone() for k, v in m(x).items()}
+            for _ in range(2):
+                b = m(x)
+                for k in a:
+                    assert torch.equal(a[k], b[k]), (force, k)
