@@ -263,7 +263,11 @@ class Pipeline:
                 x = x.to(self.dtype)
             out = model(x.contiguous(memory_format=torch.channels_last))
             logits = out['sem_logits'][..., :h, :w].float()          # logits_to_prob, engines.py:22-30
-            prob[s - lo:s - lo + x.shape[0]] = torch.sigmoid(logits) if nc == 1 else torch.softmax(logits, dim=1)
+            dst = prob[s - lo:s - lo + x.shape[0]]                   # written in place: no temporary + device copy
+            if nc == 1:
+                torch.sigmoid(logits, out=dst)
+            else:
+                torch.softmax(logits, dim=1, out=dst)
             chk += out['ctr_hmp'].float().sum(dtype=torch.float64) + out['offsets'].float().sum(dtype=torch.float64)
         return prob, chk + prob.sum(dtype=torch.float64)
 
