@@ -48,6 +48,7 @@ SIGNATURES = {
     'emp_wino_gemm_fused': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _I, _P, _P]),
     'emp_wino_output_transform': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _P]),
     'emp_chain_class': (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _c.c_double, _c.c_double, _P, _P, _P, _P]),
+    'emp_lsap_maximize': (_L, [_P, _L, _L, _P, _P]),
     'emp_slices_to_input': (_I, [_P, _L, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     'emp_pointwise_out_nhwc': (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),
     'emp_bn_relu_maxpool_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),

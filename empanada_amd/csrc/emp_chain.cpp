@@ -21,7 +21,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <limits>
 #include <unordered_map>
+#include <utility>
 #include <unordered_set>
 #include <vector>
 
@@ -30,6 +32,97 @@ typedef int64_t (*emp_lsap_fn)(const double *iou, int64_t n_rows, int64_t n_cols
 }
 
 namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Rectangular linear sum assignment, restated from the published algorithm scipy.optimize.linear_sum_assignment
+// implements (scipy 1.15.3, the routine the reference calls at matcher.py:213; D. F. Crouse, "On implementing 2D
+// rectangular assignment algorithms", IEEE TAES 52(4), 2016: shortest augmenting paths with dual variables u, v).
+// The assignment it returns among equally good ones depends on details that are therefore reproduced exactly:
+//   * more rows than columns -> the transposed problem is solved; maximisation negates the costs;
+//   * rows are augmented in order 0 .. nr-1; the list of unvisited columns starts as nc-1, nc-2, .., 0 and a visited
+//     column is replaced by the LAST element of the list;
+//   * among the unvisited columns the one with the lowest reduced path cost is taken next; on equal cost a column that
+//     is still unassigned (a new sink) replaces the current candidate, otherwise the first one found stays.
+// tests/test_sharded_gloo.py::test_native_lsap_equals_scipy compares it with scipy itself on random dense, sparse,
+// tie-heavy and rectangular matrices; chain_from_tables(lsap='scipy') keeps the library call available.
+// Returns the number of assigned pairs (min(nr, nc)), rows ascending; -1 if infeasible (cannot happen for finite costs).
+int64_t lsap_maximize(const double *cost_in, int64_t nr, int64_t nc, int64_t *rows_out, int64_t *cols_out)
+{
+    if (nr == 0 || nc == 0) return 0;
+    const bool transpose = nc < nr;
+    std::vector<double> cost((size_t)nr * nc);
+    if (transpose) {
+        for (int64_t i = 0; i < nr; ++i)
+            for (int64_t j = 0; j < nc; ++j) cost[j * nr + i] = -cost_in[i * nc + j];
+        std::swap(nr, nc);
+    } else {
+        for (int64_t q = 0; q < nr * nc; ++q) cost[q] = -cost_in[q];
+    }
+    const double inf = std::numeric_limits<double>::infinity();
+    std::vector<double> u(nr, 0.0), v(nc, 0.0), spc(nc);
+    std::vector<int64_t> path(nc, -1), col4row(nr, -1), row4col(nc, -1), remaining(nc);
+    std::vector<char> SR(nr), SC(nc);
+    for (int64_t cur = 0; cur < nr; ++cur) {
+        double min_val = 0.0;
+        int64_t num_remaining = nc;
+        for (int64_t it = 0; it < nc; ++it) remaining[it] = nc - it - 1;
+        std::fill(SR.begin(), SR.end(), 0);
+        std::fill(SC.begin(), SC.end(), 0);
+        std::fill(spc.begin(), spc.end(), inf);
+        int64_t sink = -1, i = cur;
+        while (sink == -1) {
+            int64_t index = -1;
+            double lowest = inf;
+            SR[i] = 1;
+            for (int64_t it = 0; it < num_remaining; ++it) {
+                const int64_t j = remaining[it];
+                const double r = min_val + cost[i * nc + j] - u[i] - v[j];
+                if (r < spc[j]) {
+                    path[j] = i;
+                    spc[j] = r;
+                }
+                if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) {
+                    lowest = spc[j];
+                    index = it;
+                }
+            }
+            min_val = lowest;
+            if (min_val == inf) return -1;
+            const int64_t j = remaining[index];
+            if (row4col[j] == -1) sink = j;
+            else i = row4col[j];
+            SC[j] = 1;
+            remaining[index] = remaining[--num_remaining];
+        }
+        u[cur] += min_val;
+        for (int64_t r2 = 0; r2 < nr; ++r2)
+            if (SR[r2] && r2 != cur) u[r2] += min_val - spc[col4row[r2]];
+        for (int64_t j = 0; j < nc; ++j)
+            if (SC[j]) v[j] -= min_val - spc[j];
+        int64_t j = sink;
+        while (true) {
+            const int64_t r2 = path[j];
+            row4col[j] = r2;
+            std::swap(col4row[r2], j);
+            if (r2 == cur) break;
+        }
+    }
+    if (transpose) {                        // rows of the original problem are the columns here: sort by them
+        std::vector<std::pair<int64_t, int64_t>> pairs(nr);
+        for (int64_t r2 = 0; r2 < nr; ++r2) pairs[r2] = {col4row[r2], r2};
+        std::sort(pairs.begin(), pairs.end());
+        for (int64_t q = 0; q < nr; ++q) {
+            rows_out[q] = pairs[q].first;
+            cols_out[q] = pairs[q].second;
+        }
+    } else {
+        for (int64_t r2 = 0; r2 < nr; ++r2) {
+            rows_out[r2] = r2;
+            cols_out[r2] = col4row[r2];
+        }
+    }
+    return nr;
+}
 
 struct Inst {                       // ordered instances of one slice: labels, flat component positions, areas
     std::vector<int64_t> labels, comps, seg, areas;
@@ -72,7 +165,8 @@ struct Chain {
                 for (const Entry &e : ent) iou[e.i * nm + e.j] = iou_of(e);
                 rows.resize(std::min(nt, nm));
                 cols.resize(std::min(nt, nm));
-                const int64_t k = lsap(iou.data(), nt, nm, rows.data(), cols.data());
+                const int64_t k = lsap ? lsap(iou.data(), nt, nm, rows.data(), cols.data())
+                                       : lsap_maximize(iou.data(), nt, nm, rows.data(), cols.data());
                 if (k < 0) {
                     error = 2;
                     return m;
@@ -159,6 +253,14 @@ void comp_to_inst(const Inst &inst, int64_t n_comp, std::vector<int64_t> &map)
 }  // namespace
 
 extern "C" {
+
+// scipy.optimize.linear_sum_assignment(cost, maximize=True) on a dense row-major (n_rows, n_cols) fp64 matrix: the
+// native restatement used by emp_chain_class when no callback is given.  rows_out / cols_out hold min(n_rows, n_cols)
+// entries; returns their number or -1.
+int64_t emp_lsap_maximize(const double *cost, int64_t n_rows, int64_t n_cols, int64_t *rows_out, int64_t *cols_out)
+{
+    return lsap_maximize(cost, n_rows, n_cols, rows_out, cols_out);
+}
 
 // One class.  Components are given sorted by (slice, cc label): slice t owns [bounds[t], bounds[t+1]); a component's
 // "position" is its index inside its slice.  Overlap triplets of the slice pair (t, t+1) are [tb_bounds[t],

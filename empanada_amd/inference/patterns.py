@@ -388,11 +388,14 @@ def _i64p(a):
 
 
 def chain_from_tables(host, D, labels, thing_list, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25,
-                      native=True):
+                      native=True, lsap='native'):
     """Host half of track_stack: forward + backward label propagation over the component tables of D slices.
     Returns (comp_final (n,) final label per component, first_seen {class: {label: order of first update}}).
     native=True runs the loop in C++ (emp_chain_class); native=False is the numpy statement of the same rules
-    (_ClassChain), kept as the executable specification the tests compare the native loop with."""
+    (_ClassChain), kept as the executable specification the tests compare the native loop with.
+    lsap: 'native' = the library's restatement of scipy's linear_sum_assignment (emp_lsap_maximize, no Python inside
+    the loop); 'scipy' = a callback into scipy.optimize.linear_sum_assignment itself, the routine the reference calls
+    (matcher.py:213) -- the two are compared by the tests."""
     c_slice, c_label, c_area, c_cls, trip = (host[k] for k in ('c_slice', 'c_label', 'c_area', 'c_cls', 'trip'))
     nc = len(c_slice)
     comp_final = np.zeros(nc, dtype=np.int64)
@@ -426,7 +429,8 @@ def chain_from_tables(host, D, labels, thing_list, label_divisor, merge_iou_thr=
             rc = _hip.load().emp_chain_class(D, _i64p(arrs[0]), _i64p(arrs[1]), _i64p(arrs[2]), int(is_thing),
                                              _i64p(arrs[3]), _i64p(arrs[4]), _i64p(arrs[5]), _i64p(arrs[6]), int(l),
                                              int(label_divisor), float(merge_iou_thr), float(merge_ioa_thr),
-                                             ctypes.cast(_LSAP_C, ctypes.c_void_p), _i64p(out), _i64p(seen),
+                                             ctypes.cast(_LSAP_C, ctypes.c_void_p) if lsap == 'scipy' else None,
+                                             _i64p(out), _i64p(seen),
                                              ctypes.byref(n_seen))
             if rc == 1:
                 raise ValueError("attempt to get argmax of an empty sequence")

@@ -472,6 +472,10 @@ int emp_track_clip(const uint64_t *key, const int64_t *len, int64_t n, int64_t l
  * Returns 0; 1 where the reference raises ValueError (ioa_thr <= 0 and an empty target slice); 2 lsap failed.  */
 typedef int64_t (*emp_lsap_fn)(const double *iou, int64_t n_rows, int64_t n_cols, int64_t *rows_out,
                                int64_t *cols_out);
+/* lsap == NULL: the library's own restatement of that routine (emp_lsap_maximize: shortest augmenting paths after
+ * Crouse 2016 with scipy 1.15's column order and tie rule, checked against scipy itself by
+ * tests/test_sharded_gloo.py::test_native_lsap_equals_scipy) -- no Python in the loop. */
+int64_t emp_lsap_maximize(const double *cost, int64_t n_rows, int64_t n_cols, int64_t *rows_out, int64_t *cols_out);
 int emp_chain_class(int64_t D, const int64_t *bounds, const int64_t *comp_label, const int64_t *comp_area,
                     int is_thing, const int64_t *tb_bounds, const int64_t *pa, const int64_t *pb,
                     const int64_t *tv, int64_t class_id, int64_t label_divisor, double iou_thr, double ioa_thr,

@@ -320,3 +320,55 @@ def test_native_chain_error_and_empty_cases():
     for native in (True, False):
         with pytest.raises(ValueError):
             chain_from_tables(host, 3, [1], [1], DIV, 0.25, 0.0, native=native)
+
+
+def test_native_lsap_equals_scipy():
+    """emp_lsap_maximize (the restatement of the algorithm scipy.optimize.linear_sum_assignment implements) against
+    scipy itself: dense, sparse IoU-like, tie-heavy integer, all-zero and rectangular matrices -- the returned
+    assignment, not just its value, must be identical, because ties decide which instance keeps a label"""
+    from scipy.optimize import linear_sum_assignment
+    from empanada_amd import _hip
+    lib = _hip.load()
+    rng = np.random.default_rng(11)
+
+    def native(m):
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        k = min(m.shape)
+        r, c = np.zeros(k, np.int64), np.zeros(k, np.int64)
+        n = lib.emp_lsap_maximize(m.ctypes.data, m.shape[0], m.shape[1], r.ctypes.data, c.ctypes.data)
+        return r[:n], c[:n]
+
+    for trial in range(6000):
+        nr, nc = (int(v) for v in rng.integers(1, 48, 2))
+        kind = trial % 6
+        if kind == 0:
+            m = rng.random((nr, nc))
+        elif kind == 1:
+            m = rng.random((nr, nc)) * (rng.random((nr, nc)) < 0.1)
+        elif kind == 2:
+            m = rng.integers(0, 3, (nr, nc)).astype(float)
+        elif kind == 3:
+            m = rng.integers(0, 2, (nr, nc)) * 0.5
+        elif kind == 4:
+            m = np.round(rng.random((nr, nc)), 1) * (rng.random((nr, nc)) < 0.3)
+        else:
+            m = np.zeros((nr, nc))
+        a, b = linear_sum_assignment(m, maximize=True), native(m)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (kind, m.shape)
+    for trial in range(40):                                   # the chain's sizes: ~200 components per slice
+        nr, nc = (int(v) for v in rng.integers(150, 260, 2))
+        m = rng.random((nr, nc)) * (rng.random((nr, nc)) < 0.01)
+        if trial % 2:
+            m = np.round(m, 1)
+        a, b = linear_sum_assignment(m, maximize=True), native(m)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_chain_with_native_lsap_equals_chain_with_scipy(seed):
+    pan = _blobby_stack(seed, n=90)
+    host, _ = cpu_tables(pan, [1, 2], [1])
+    a, fa = chain_from_tables(host, pan.shape[0], [1, 2], [1], DIV, 0.25, 0.25, lsap='native')
+    b, fb = chain_from_tables(host, pan.shape[0], [1, 2], [1], DIV, 0.25, 0.25, lsap='scipy')
+    np.testing.assert_array_equal(a, b)
+    assert {k: list(v.items()) for k, v in fa.items()} == {k: list(v.items()) for k, v in fb.items()}
