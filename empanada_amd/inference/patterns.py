@@ -21,7 +21,7 @@ import torch.distributed as dist
 from scipy.optimize import linear_sum_assignment
 
 from .. import _hip
-from ..array_utils import merge_boxes, numpy_fill_instances
+from ..array_utils import numpy_fill_instances
 from ..consensus import merge_objects_from_trackers, merge_semantic_from_trackers
 from ..zarr_utils import zarr_fill_instances
 from . import filters
