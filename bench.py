@@ -326,7 +326,7 @@ def build_inputs(D, S, device, seed_offset=0, things=1):
     return vol, heads, int(cls.shape[0] - 1)
 
 
-def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None):
+def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None, things=1):
     """cubic volume shared by all ranks; every rank holds the whole uint8 EM volume (1 GiB at 1024^3; each plane is a
     strided view of it) and the planted heads of its own contiguous block of slices per plane"""
     from empanada_amd import synthetic as SY
@@ -336,7 +336,8 @@ def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None):
     b = shard_bounds(S, world)
     lo, hi = int(b[rank]), int(b[rank + 1])
     box = {}
-    t = threading.Thread(target=lambda: box.update(lab=SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321)))
+    t = threading.Thread(target=lambda: box.update(lab=SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321,
+                                                                         n_classes=things)))
     t.start()                                      # numpy on the host, while the EM volume is drawn and uploaded
     dv = DeviceVolume(SY.em_volume(shape, seed=1234), NORM['mean'], NORM['std'], 16, device)
     t.join()
@@ -350,7 +351,8 @@ def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None):
         stacks[axis] = (dv, axis, lo, hi)          # the rank's block of the plane: a strided view of the volume
         parts = {'sem': [], 'ctr_hmp': [], 'offsets': []}
         for s in range(lo, hi, chunk):
-            h = SY.planted_heads(lab_dev, cls, axis, device=device, slices=slice(s, min(hi, s + chunk)), seed=99 + s)
+            h = SY.planted_heads(lab_dev, cls, axis, device=device, slices=slice(s, min(hi, s + chunk)), seed=99 + s,
+                                 n_classes=things)
             for k in parts:
                 parts[k].append(h[k])
         heads[axis] = {k: torch.cat(v, dim=0).contiguous() for k, v in parts.items()}
@@ -365,7 +367,8 @@ def postprocess_planes(heads, shape3d, writer, stages, between=None, before=None
     -> consensus -> filters -> fill of the rank's z-slab -> pinned host memory -> zarr chunk files.  `between(i)` is called once plane
     i's device tables are on the host (the driver queues the next forward there), `before(axis)` right before plane
     `axis` is touched (the driver makes the post-processing stream wait for that plane's forward there).
-    Returns (#consensus instances, the rank's slab of the labelled volume on the device, (z0, z1))."""
+    writer: {class: SlabWriter} or None.
+    Returns (#consensus instances, {class: the rank's slab of that class's labelled volume on the device}, (z0, z1))."""
     from empanada_amd.inference import sharded
     planes, base = {}, 0
     for i, axis in enumerate(('xy', 'xz', 'yz')):
@@ -390,15 +393,15 @@ def postprocess_planes(heads, shape3d, writer, stages, between=None, before=None
                                               CONSENSUS['pixel_vote_thr'], CONSENSUS['cluster_iou_thr'],
                                               CONSENSUS['bypass'], FILTERS['min_size'], FILTERS['min_span'])
     t1 = time.perf_counter()
-    vol = vols[1]
     if writer is not None:                             # slab -> pinned host buffer -> chunk files of the zarr array
-        buf = writer.next_buffer()                     # (written by a thread pool while the GPU runs the next pass)
-        buf.copy_(vol.view(torch.int32), non_blocking=True)
+        for c in LABELS:                               # (written by a thread pool while the GPU runs the next pass)
+            writer[c].next_buffer().copy_(vols[c].view(torch.int32), non_blocking=True)
         torch.cuda.current_stream().synchronize()      # the post stream only: a prefetched forward keeps running
-        writer.submit()
+        for c in LABELS:
+            writer[c].submit()
     stages['consensus_and_fill'] = stages.get('consensus_and_fill', 0) + t1 - t0
     stages['to_host_and_submit_write'] = stages.get('to_host_and_submit_write', 0) + time.perf_counter() - t1
-    return int(cons[1].alive.sum()), vol, zs
+    return sum(int(cons[c].alive.sum()) for c in LABELS), vols, zs
 
 
 def orthoplane_step(pipe, stacks, heads, shape3d, writer, stages, first=None, prefetch_next=False):
@@ -469,8 +472,9 @@ def cpu_baseline_ortho(args, n, cores):
     shape = (n, n, n)
     torch.set_num_threads(cores)
     em = SY.em_volume(shape, seed=1234)
-    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321)
-    heads = {a: SY.planted_heads(lab, cls, a, seed=99) for a in ('xy', 'xz', 'yz')}
+    T = len(LABELS)
+    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321, n_classes=T)
+    heads = {a: SY.planted_heads(lab, cls, a, seed=99, n_classes=T) for a in ('xy', 'xz', 'yz')}
     model = build_model(args.model).eval()
     div, things = ENGINE['label_divisor'], ENGINE['thing_list']
     t0 = time.perf_counter()
@@ -483,7 +487,7 @@ def cpu_baseline_ortho(args, n, cores):
         with torch.no_grad():
             for i in range(n):
                 out = model(x[i:i + 1])
-                _ = torch.sigmoid(out['sem_logits'])
+                _ = torch.sigmoid(out['sem_logits']) if T == 1 else torch.softmax(out['sem_logits'], dim=1)
         t_conv += time.perf_counter() - tc
         sem, ctr, off = (heads[axis][k].numpy() for k in ('sem', 'ctr_hmp', 'offsets'))
         pans = OP.engine3d_stack([sem[t:t + 1] for t in range(n)], [ctr[t:t + 1] for t in range(n)],
@@ -497,22 +501,31 @@ def cpu_baseline_ortho(args, n, cores):
         for tr in trackers[axis]:
             OS.remove_small_objects(tr, FILTERS['min_size'])
             OS.remove_pancakes(tr, FILTERS['min_span'])
-    cts = [t for axis in ('xy', 'xz', 'yz') for t in trackers[axis] if t.class_id == 1]
-    con = OC.create_instance_consensus(cts, CONSENSUS['pixel_vote_thr'], CONSENSUS['cluster_iou_thr'], CONSENSUS['bypass'])
-    OS.remove_small_objects(con, FILTERS['min_size'])
-    OS.remove_pancakes(con, FILTERS['min_span'])
-    ref = OR.numpy_fill_instances(np.zeros(shape, np.uint32), con.instances)
+    refs, n_inst = {}, 0
+    for c in LABELS:
+        cts = [t for axis in ('xy', 'xz', 'yz') for t in trackers[axis] if t.class_id == c]
+        con = OC.create_instance_consensus(cts, CONSENSUS['pixel_vote_thr'], CONSENSUS['cluster_iou_thr'],
+                                           CONSENSUS['bypass'])
+        OS.remove_small_objects(con, FILTERS['min_size'])
+        OS.remove_pancakes(con, FILTERS['min_span'])
+        refs[c] = OR.numpy_fill_instances(np.zeros(shape, np.uint32), con.instances)
+        n_inst += len(con.instances)
     dt = time.perf_counter() - t0
     # the HIP path on exactly the same heads
     dev_heads = {a: {k: v.cuda().contiguous() for k, v in heads[a].items()} for a in heads}
-    _, vol, _ = postprocess_planes(dev_heads, shape, None, {})
-    got = vol.view(torch.int32).cpu().numpy().astype(np.uint32)
-    pq, n_gt, n_pred, n_match = volume_pq(ref, got)
+    _, vols, _ = postprocess_planes(dev_heads, shape, None, {})
+    same, pqs, matched = True, [], [0, 0, 0]
+    for c in LABELS:
+        got = vols[c].view(torch.int32).cpu().numpy().astype(np.uint32)
+        pq, n_gt, n_pred, n_match = volume_pq(refs[c], got)
+        same = same and bool(np.array_equal(refs[c], got))
+        pqs.append(pq)
+        matched = [matched[0] + n_gt, matched[1] + n_pred, matched[2] + n_match]
     return {'value': round(float(n) ** 3 / dt / 1e6, 4), 'unit': 'Mvox/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n}^3 corner sub-volume of the same recipe: all three planes ({3 * n} slices of {n}x{n}) + '
                       f'consensus + fill; conv {t_conv:.1f}s of {dt:.1f}s',
-            'objects': int(len(con.instances)), 'pq_vs_cpu_ref': round(pq, 6),
-            'ids_identical': bool(np.array_equal(ref, got)), 'instances_cpu_gpu_matched': [n_gt, n_pred, n_match]}
+            'objects': int(n_inst), 'pq_vs_cpu_ref': round(min(pqs), 6),
+            'ids_identical': same, 'instances_cpu_gpu_matched': matched}
 
 
 def main_orthoplane(args, device, rank, world):
@@ -520,7 +533,7 @@ def main_orthoplane(args, device, rank, world):
     from empanada_amd import _hip
     S = args.size
     log(f'orthoplane: building inputs {S}^3 (rank {rank}/{world})')
-    stacks, heads, n_obj, slice0 = build_inputs_ortho(S, device, rank, world)
+    stacks, heads, n_obj, slice0 = build_inputs_ortho(S, device, rank, world, things=len(LABELS))
     log(f'inputs ready ({n_obj} planted objects)')
     pipe = Pipeline(args, device)
     if not args.no_tune:
@@ -533,13 +546,15 @@ def main_orthoplane(args, device, rank, world):
     zb = shard_bounds(S, world)                      # every rank paints, copies out and WRITES its own z-slab
     out_dir = args.out or os.path.join('/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir(),
                                        f'emp_bench_{os.environ.get("MASTER_PORT", os.getpid())}.zarr')
-    if rank == 0:                                    # scripts/pdl_inference3d.py:228-231
-        ZarrV2Group(out_dir).create_dataset('mito_pred', shape=shape3d, dtype=np.uint32, overwrite=True,
-                                            chunks=(1, None, None))
+    names = {c: ('mito_pred' if len(LABELS) == 1 else f'class{c}_pred') for c in LABELS}
+    if rank == 0:                                    # scripts/pdl_inference3d.py:228-231: one dataset per class
+        grp = ZarrV2Group(out_dir)
+        for c in LABELS:
+            grp.create_dataset(names[c], shape=shape3d, dtype=np.uint32, overwrite=True, chunks=(1, None, None))
     if world > 1:
         dist.barrier()
-    dataset = open_zarr(os.path.join(out_dir, 'mito_pred'))
-    writer = SlabWriter(dataset, int(zb[rank]), (int(zb[rank + 1] - zb[rank]), S, S), torch.int32, threads=4)
+    writer = {c: SlabWriter(open_zarr(os.path.join(out_dir, names[c])), int(zb[rank]),
+                            (int(zb[rank + 1] - zb[rank]), S, S), torch.int32, threads=4) for c in LABELS}
 
     def barrier():
         torch.cuda.synchronize()
@@ -560,7 +575,8 @@ def main_orthoplane(args, device, rank, world):
         chk, n_found, first = orthoplane_step(pipe, stacks, heads, shape3d, writer, stages, first,
                                               prefetch_next=(k + 1 < args.steps) and not args.no_pipeline)
         chks.append(chk)
-    writer.drain()                                   # the last pass's chunk files are on disk
+    for w in writer.values():
+        w.drain()                                    # the last pass's chunk files are on disk
     barrier()
     dt = time.perf_counter() - t0
     log(f'timed {args.steps} steps in {dt:.2f}s')
@@ -570,16 +586,20 @@ def main_orthoplane(args, device, rank, world):
         t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    writer.close()
+    for w in writer.values():
+        w.close()
     if rank != 0:
         return
-    written = open_zarr(os.path.join(out_dir, 'mito_pred'))
+    written = open_zarr(os.path.join(out_dir, names[LABELS[0]]))
     mid = written[S // 2]                            # read one slice back from the store
-    out_check = {'path': out_dir, 'dataset': 'mito_pred', 'chunks': list(written.chunks), 'dtype': str(written.dtype),
-                 'labels_in_slice_read_back': int(len(np.unique(mid)) - 1)}
+    out_check = {'path': out_dir, 'datasets': [names[c] for c in LABELS], 'chunks': list(written.chunks),
+                 'dtype': str(written.dtype), 'labels_in_slice_read_back': int(len(np.unique(mid)) - 1)}
     chks = [float(c) for c in chks]
     vox_launch = float(S) ** 3 / world               # voxels one post-processing launch covers (a rank's block of a plane)
-    thing_frac = float((heads['xy']['sem'] >= ENGINE['confidence_thr']).float().mean().item())
+    if len(LABELS) == 1:
+        thing_frac = float((heads['xy']['sem'] >= ENGINE['confidence_thr']).float().mean().item())
+    else:
+        thing_frac = float((heads['xy']['sem'].argmax(dim=1) > 0).float().mean().item())
     roof, per_call, per_pass = roofline_block(prof, vox_launch, thing_frac, args.steps, dense_passes=1)
     fwd_ms_pass = sum(v for k, v in per_pass.items() if k in DENSE_KERNELS)
     res = {
@@ -589,7 +609,8 @@ def main_orthoplane(args, device, rank, world):
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f32' if args.dtype == 'fp32' else args.dtype, 'data': 'synthetic',
         'config': {'workload': f'orthoplane (xy/xz/yz) inference + instance consensus, {S}^3 uint8 volume '
-                               f'(BASELINE configs[{3 if S >= 1024 else 2}] volume), {MODELS[args.model]} C=1 fp32 '
+                               f'(BASELINE configs[{3 if S >= 1024 else 2}] volume), {MODELS[args.model]} '
+                               f'C={1 if len(LABELS) == 1 else len(LABELS) + 1} fp32 '
                                f'forward on every slice of every plane + HIP post-processing on planted heads '
                                f'(ks=7, full-res heads), {n_obj} planted objects, slices of every plane sharded over '
                                f'{world} rank(s)',
@@ -599,7 +620,7 @@ def main_orthoplane(args, device, rank, world):
                       'hand_written_dense_ms_per_pass_rank0': round(fwd_ms_pass, 1),
                       'forward_TFLOPs_if_gpu_bound': round(3 * FLOPS_PER_VOXEL_PDL_R50 * float(S) ** 3 / world
                                                            / (dt / args.steps) / 1e12, 2)
-                      if args.model == 'pdl_r50' else None,
+                      if args.model == 'pdl_r50' and len(LABELS) == 1 else None,
                       'pipelined': not args.no_pipeline, 'conv_impls': pipe.tuned},
         'forward_checksum': chks[-1], 'forward_checksum_stable': bool(all(c == chks[0] for c in chks)),
         'hip_calls_ms': per_call, 'hip_ms_per_pass': per_pass, 'roofline': roof,
@@ -866,7 +887,6 @@ def main():
     torch.backends.cudnn.benchmark = True
 
     if args.things > 1:
-        assert args.mode == 'stack', '--things > 1 is implemented for the stack mode'
         LABELS[:] = list(range(1, args.things + 1))
         ENGINE['thing_list'] = list(LABELS)
     (main_orthoplane if args.mode == 'orthoplane' else main_stack)(args, device, rank, world)

@@ -159,7 +159,8 @@ def test_orthoplane_512_cubed_properties_and_oracle_subvolume(tmp_path):
     ds = ZarrV2Group(str(tmp_path / 'o.zarr')).create_dataset('mito_pred', shape=(S2,) * 3, dtype=np.uint32,
                                                                 chunks=(1, None, None))
     writer = SlabWriter(ds, 0, (S2,) * 3, torch.int32)
-    n_found, vol, zs = bench.postprocess_planes(heads, (S2,) * 3, writer, {})
+    n_found, vols, zs = bench.postprocess_planes(heads, (S2,) * 3, {1: writer}, {})
+    vol = vols[1]
     writer.close()
     assert zs == (0, S2) and n_found > 0.9 * n_obj
     v = vol.view(torch.int32)
@@ -168,7 +169,8 @@ def test_orthoplane_512_cubed_properties_and_oracle_subvolume(tmp_path):
     assert ids[0] == 0 and len(ids) - 1 == n_found
     # second pass: identical, and its tables give the conservation check
     from empanada_amd.inference import sharded
-    n2, vol2, _ = bench.postprocess_planes(heads, (S2,) * 3, None, {})
+    n2, vols2, _ = bench.postprocess_planes(heads, (S2,) * 3, None, {})
+    vol2 = vols2[1]
     assert n2 == n_found and torch.equal(vol2.view(torch.int32), v)
     planes, base = {}, 0
     for axis in ('xy', 'xz', 'yz'):
@@ -194,7 +196,7 @@ def test_orthoplane_512_cubed_properties_and_oracle_subvolume(tmp_path):
     back = open_zarr(ds.path)
     for z in (0, 1, S2 // 2, S2 - 1):
         np.testing.assert_array_equal(back[z], v[z].cpu().numpy().astype(np.uint32))
-    del heads, vol, vol2, planes
+    del heads, vol, vol2, vols, vols2, planes
     torch.cuda.empty_cache()
 
     # ---- corner sub-volume against the oracle
@@ -222,6 +224,7 @@ def test_orthoplane_512_cubed_properties_and_oracle_subvolume(tmp_path):
     OS.remove_pancakes(con, bench.FILTERS['min_span'])
     exp = OR.numpy_fill_instances(np.zeros(shape, np.uint32), con.instances)
     dev = {a: {k: t.cuda().contiguous() for k, t in sub[a].items()} for a in sub}
-    _, got, _ = bench.postprocess_planes(dev, shape, None, {})
+    _, gots, _ = bench.postprocess_planes(dev, shape, None, {})
+    got = gots[1]
     assert exp.max() >= 3
     np.testing.assert_array_equal(got.view(torch.int32).cpu().numpy().astype(np.uint32), exp)

@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 _hip.PROFILE = {}
 REPS = 3
 for _ in range(REPS):
-    n_found, vol, _ = bench.postprocess_planes(heads, (S, S, S), None, {})
+    n_found, vols, _ = bench.postprocess_planes(heads, (S, S, S), None, {})
 torch.cuda.synchronize()
 prof, _hip.PROFILE = _hip.PROFILE, None
 vox = float(S) ** 3
