@@ -124,3 +124,94 @@ def test_argument_errors_are_loud():
     with pytest.raises(_hip.HipError):     # heads at a resolution the step does not explain
         panoptic_stack(torch.rand(2, 1, 30, 30).cuda(), torch.rand(2, 1, 30, 30).cuda(), torch.rand(2, 2, 30, 30).cuda(),
                        coarse_boundaries=True, **KW)
+
+
+# ------------------------------------------------------------------------------------------------ orthoplane edges
+def _ortho_oracle(heads_by_axis, shape, kw, min_size, min_span, vote=2, iou=0.75):
+    from oracle import consensus as OC
+    from oracle import postprocess as OP
+    from oracle import rle_ops as OR
+    from oracle import rle_seg as OS
+    trackers = OS.create_axis_trackers(['xy', 'xz', 'yz'], [1], kw['label_divisor'], shape)
+    for axis in ('xy', 'xz', 'yz'):
+        sem, ctr, off = heads_by_axis[axis]
+        n = sem.shape[0]
+        pans = OP.engine3d_stack([sem[t:t + 1] for t in range(n)], [ctr[t:t + 1] for t in range(n)],
+                                 [off[t:t + 1] for t in range(n)], coarse_boundaries=False, render=True, **kw)
+        pans = [p.squeeze() for p in pans]
+        matchers = OS.create_matchers([1], kw['label_divisor'], 0.25, 0.25)
+        stack = OS.forward_matching(pans, matchers, [1], kw['label_divisor'], [1])
+        for idx, rs in OS.backward_matching(stack, matchers, n):
+            OS.update_trackers(rs, idx, trackers[axis])
+        OS.finish_tracking(trackers[axis])
+        for tr in trackers[axis]:
+            OS.remove_small_objects(tr, min_size)
+            OS.remove_pancakes(tr, min_span)
+    con = OC.create_instance_consensus([t for a in ('xy', 'xz', 'yz') for t in trackers[a]], vote, iou, False)
+    OS.remove_small_objects(con, min_size)
+    OS.remove_pancakes(con, min_span)
+    return OR.numpy_fill_instances(np.zeros(shape, np.uint32), con.instances), len(con.instances)
+
+
+def _ortho_product(heads_by_axis, shape, kw, min_size, min_span, vote=2, iou=0.75):
+    from empanada_amd.inference import sharded
+    planes, base = {}, 0
+    for axis in ('xy', 'xz', 'yz'):
+        sem, ctr, off = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in heads_by_axis[axis])
+        pan = sharded.sharded_panoptic_stack(sem, ctr, off, coarse_boundaries=False, **kw)
+        planes[axis] = sharded.track_plane(pan, axis, shape, [1], [1], kw['label_divisor'], 0.25, 0.25, inst_base=base)
+        base += planes[axis].n_inst
+    cons, vols, _ = sharded.consensus_volume(planes, shape, [1], [1], vote, iou, False, min_size, min_span)
+    return vols[1].cpu().numpy().astype(np.uint32), int(cons[1].alive.sum()), planes
+
+
+def _heads_of(lab, cls, drop_plane=None):
+    out = {}
+    for axis in ('xy', 'xz', 'yz'):
+        h = SY.planted_heads(lab, cls, axis, seed=7)
+        sem, ctr, off = (h[k].numpy() for k in ('sem', 'ctr_hmp', 'offsets'))
+        if axis == drop_plane:                       # this plane sees nothing at all
+            sem = np.full_like(sem, 0.05)
+            ctr = np.zeros_like(ctr)
+            off = np.zeros_like(off)
+        out[axis] = (sem, ctr, off)
+    return out
+
+
+def test_orthoplane_empty_volume():
+    """no object anywhere: three empty planes, empty run tables, empty consensus, zero volume -- no kernel may trip over
+    a zero-length table"""
+    shape = (12, 16, 20)
+    lab = np.zeros(shape, np.uint16)
+    cls = np.zeros(1, np.uint8)
+    heads = _heads_of(lab, cls)
+    for axis in heads:                               # keep the noise below the threshold everywhere
+        heads[axis] = (np.minimum(heads[axis][0], 0.2), heads[axis][1], heads[axis][2])
+    got, n, planes = _ortho_product(heads, shape, KW, 10, 2)
+    assert n == 0 and got.shape == shape and not got.any()
+    assert all(p.n_inst == 0 and p.n_runs == 0 for p in planes.values())
+    exp, ne = _ortho_oracle(heads, shape, KW, 10, 2)
+    assert ne == 0 and not exp.any()
+
+
+def test_orthoplane_single_object_and_a_blind_plane():
+    """one object: (a) seen by all three planes; (b) one plane blind -- two votes still make the consensus
+    (pixel_vote_thr 2 of 3, min_cluster_size 2); (c) two planes blind -- nothing survives.  Bit-identical to the oracle."""
+    shape = (24, 28, 32)
+    lab = np.zeros(shape, np.uint16)
+    zz, yy, xx = np.ogrid[:24, :28, :32]
+    lab[((zz - 12) / 7.0) ** 2 + ((yy - 14) / 8.0) ** 2 + ((xx - 15) / 9.0) ** 2 <= 1.0] = 1
+    cls = np.array([0, 1], np.uint8)
+    for drop, expect in ((None, 1), ('xz', 1)):
+        heads = _heads_of(lab, cls, drop)
+        got, n, _ = _ortho_product(heads, shape, KW, 50, 3)
+        exp, ne = _ortho_oracle(heads, shape, KW, 50, 3)
+        assert n == ne == expect, (drop, n, ne)
+        np.testing.assert_array_equal(got, exp)
+        assert got.max() == 1 and (got > 0).sum() > 0.8 * (lab > 0).sum()
+    heads = _heads_of(lab, cls, 'xz')
+    blind = _heads_of(lab, cls, 'yz')
+    heads['yz'] = blind['yz']
+    got, n, _ = _ortho_product(heads, shape, KW, 50, 3)
+    exp, ne = _ortho_oracle(heads, shape, KW, 50, 3)
+    assert n == ne == 0 and not got.any() and not exp.any()
