@@ -39,6 +39,8 @@ __all__ = ['merge_objects_from_trackers', 'merge_semantic_from_trackers', 'merge
 
 MIN_OVERLAP = 100
 MIN_IOU = 1e-2
+# which branches of consensus_objects ran (tests assert that their random scenes reach all of them)
+BRANCH_COUNTS = {'fast_components': 0, 'general_components': 0, 'extra_memberships': 0, 'overlap_joins': 0}
 
 
 class RunStore:
@@ -316,6 +318,8 @@ def consensus_objects(src, boxes, areas, store, n_votes, pixel_vote_thr=2, clust
         clusters_of = {int(comp_rank[comp_of[f]]): [c for c in cl if len(c) >= min_cluster_size]
                        for f, cl in clusters_of.items()}
 
+    BRANCH_COUNTS['general_components'] += int(general.sum())
+    BRANCH_COUNTS['fast_components'] += int((eligible & ~general).sum())
     # ---- groups to vote on: one per cluster, component by component
     slots = np.where(eligible, 1, 0).astype(np.int64)
     for r, cl in clusters_of.items():
@@ -360,6 +364,7 @@ def consensus_objects(src, boxes, areas, store, n_votes, pixel_vote_thr=2, clust
     per_obj[sidx[prim]] = m_group[first_row[prim]]
     v_st, v_ln, v_grp = store.st, store.ln, store.expand(per_obj)
     extra = np.setdiff1d(rows, first_row[prim], assume_unique=True)
+    BRANCH_COUNTS['extra_memberships'] += int(len(extra))
     if len(extra):
         off_h = store.off.cpu().numpy()
         lo_e, hi_e = off_h[sidx[m_node[extra]]], off_h[sidx[m_node[extra]] + 1]
@@ -409,6 +414,7 @@ def consensus_objects(src, boxes, areas, store, n_votes, pixel_vote_thr=2, clust
             root[g] = r
     else:
         root = np.arange(n_groups)
+    BRANCH_COUNTS['overlap_joins'] += int(joined_any)
     heads = nonempty & (root == np.arange(n_groups))
     final_of[heads] = np.arange(int(heads.sum()))
     final_of[nonempty] = final_of[root[nonempty]]

@@ -666,3 +666,90 @@ def test_forward_is_deterministic_from_run_to_run():
                 b = m(x)
                 for k in a:
                     assert torch.equal(a[k], b[k]), (force, k)
+
+
+def _random_tracker_volumes(seed, shape=(36, 40, 44)):
+    """three label volumes of the same scene as three imperfect observers would see it: objects dropped, shifted by a
+    voxel or two, eroded, split in two, or fused with a neighbour -- so that pair IoUs fall on both sides of the
+    cluster cut, hubs link several clusters and voted clusters overlap (every branch of the consensus)"""
+    rng = np.random.default_rng(seed)
+    base, _ = SY.planted_labels(shape, fill=0.3, rmin=3, rmax=8, seed=seed + 1000)
+    n = int(base.max())
+    vols = []
+    for t in range(3):
+        v = np.zeros(shape, dtype=np.int64)
+        for i in range(1, n + 1):
+            m = base == i
+            if not m.any():
+                continue
+            mode = rng.integers(0, 8)
+            if mode == 0:
+                continue                                               # missed
+            if mode == 1:
+                m = np.roll(m, int(rng.integers(-2, 3)), axis=int(rng.integers(0, 3)))
+            elif mode == 2:                                            # eroded along one axis
+                ax = int(rng.integers(0, 3))
+                m = m & np.roll(m, 1, axis=ax) & np.roll(m, -1, axis=ax)
+            elif mode == 3:                                            # split in two by a gap
+                idx = np.nonzero(m)
+                ax = int(rng.integers(0, 3))
+                cut = int(np.median(idx[ax]))
+                sl = [slice(None)] * 3
+                sl[ax] = cut
+                m = m.copy()
+                m[tuple(sl)] = False
+            lab = 1000 + i
+            if mode == 4 and i > 1:
+                lab = 1000 + i - 1                                     # fused with the previous object's label
+            v[m] = lab
+        vols.append(v)
+    return vols
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_consensus_random_scenes_equal_oracle(seed):
+    """differential test of merge_objects_from_trackers (box screening, pair intersections, cluster graph incl. shared
+    hubs, votes, overlap joins on the GPU + tables) against the oracle (pinned to the reference by its six KATs) on
+    random imperfect observers, for the vote / IoU / bypass settings the reference's tests use"""
+    from empanada_amd import consensus as CO
+    from empanada_amd.inference import rle, tracker
+    from oracle import consensus as OC
+    from oracle import rle_seg as OS
+    vols = _random_tracker_volumes(seed)
+    shape = vols[0].shape
+    trs, otrs = [], []
+    for ti, v in enumerate(vols):
+        tr = tracker.InstanceTracker(1, 1000, shape, axis='xy')
+        otr = OS.InstanceTracker(1, 1000, shape, 'xy')
+        segs, _ = rle.stack_to_rle_segs(torch.from_numpy(v.astype(np.int32)).cuda().view(torch.uint32), [1], 1000, [1],
+                                        force_connected=True)
+        for z in range(shape[0]):
+            tr.update(segs[z][1], z)
+            otr.update(OS.pan_seg_to_rle_seg(v[z], [1], 1000, [1], force_connected=True)[1], z)
+        tr.finish()
+        otr.finish()
+        assert_instances_equal(tr.instances, otr.instances, check_order=False)
+        trs.append(tr)
+        otrs.append(otr)
+    n_cases = 0
+    for vote, iou_thr, bypass in ((2, 0.75, False), (2, 0.75, True), (1, 0.75, False), (3, 0.75, False), (2, 0.1, False),
+                                  (1, 0.75, True), (2, 0.5, False)):
+        try:
+            exp = OC.merge_objects_from_trackers(otrs, vote, iou_thr, bypass)
+        except Exception as e:                                     # the reference's single-range join failure etc.
+            with pytest.raises(type(e)):
+                CO.merge_objects_from_trackers(trs, vote, iou_thr, bypass)
+            continue
+        got = CO.merge_objects_from_trackers(trs, vote, iou_thr, bypass)
+        assert_instances_equal(got, exp)
+        n_cases += 1
+    assert n_cases >= 4
+
+
+def test_consensus_random_scenes_reach_every_branch():
+    """(runs after the parametrised cases above) the random scenes exercised the array fast path, the literal
+    cluster-graph path, hubs shared by several clusters and the overlap joins"""
+    from empanada_amd import consensus as CO
+    c = CO.BRANCH_COUNTS
+    assert c['fast_components'] > 10 and c['general_components'] > 10, c
+    assert c['extra_memberships'] > 0 and c['overlap_joins'] > 0, c
