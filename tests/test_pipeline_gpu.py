@@ -753,3 +753,48 @@ def test_consensus_random_scenes_reach_every_branch():
     c = CO.BRANCH_COUNTS
     assert c['fast_components'] > 10 and c['general_components'] > 10, c
     assert c['extra_memberships'] > 0 and c['overlap_joins'] > 0, c
+
+
+def _blobby_stack(seed, shape=(20, 36, 40), n=45, div=1000):
+    """random boxes that move, split and merge from slice to slice and touch each other (also across row ends):
+    instances made of several components per slice, runs of one instance that are contiguous in flat index, labels
+    that merge through the IoA rule -- what the planted ellipsoids rarely produce"""
+    rng = np.random.default_rng(seed)
+    D, H, W = shape
+    pan = np.zeros(shape, dtype=np.int64)
+    for _ in range(n):
+        z0, z1 = sorted(rng.integers(0, D, 2))
+        y, x = rng.integers(0, H - 8), rng.integers(0, W - 8)
+        h, w = rng.integers(3, 12), rng.integers(3, 12)
+        for z in range(z0, z1 + 1):
+            y = int(np.clip(y + rng.integers(-2, 3), 0, H - h))
+            x = int(np.clip(x + rng.integers(-2, 3), 0, W - w))
+            pan[z, y:y + h, x:x + w] = div + 1 + rng.integers(0, 3)
+            if rng.random() < 0.2:
+                pan[z, y + h // 2, x:x + w] = 0                     # split
+            if rng.random() < 0.1:
+                pan[z, y, :] = div + 1 + rng.integers(0, 3)           # a full-width row: runs wrap over the row end
+    return pan
+
+
+@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('axis', ['xy', 'xz', 'yz'])
+def test_track_stack_random_stacks_equal_oracle(seed, axis):
+    """differential test of the whole per-plane chain on the device (runs, components, reduced overlaps, native chain
+    with the native Hungarian step, run lift + merge + sort, materialised trackers) against the oracle's per-slice
+    protocol (pan_seg_to_rle_seg -> forward / backward matching -> InstanceTracker.update / finish), all three planes"""
+    from empanada_amd.inference import patterns as PA
+    from oracle import rle_seg as OS
+    pan = _blobby_stack(seed)
+    D, H, W = pan.shape
+    shape3d = {'xy': (D, H, W), 'xz': (H, D, W), 'yz': (H, W, D)}[axis]
+    trs = PA.track_stack(torch.from_numpy(pan.astype(np.int32)).cuda().view(torch.uint32), axis, shape3d, [1], [1], 1000,
+                         0.25, 0.25)
+    matchers = OS.create_matchers([1], 1000, 0.25, 0.25)
+    stack = OS.forward_matching([pan[z] for z in range(D)], matchers, [1], 1000, [1])
+    otr = OS.create_axis_trackers([axis], [1], 1000, shape3d)[axis]
+    for idx, rs in OS.backward_matching(stack, matchers, D):
+        OS.update_trackers(rs, idx, otr)
+    OS.finish_tracking(otr)
+    assert len(otr[0].instances) > 5
+    assert_instances_equal(trs[0].instances, otr[0].instances)
