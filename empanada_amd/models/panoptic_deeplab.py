@@ -727,6 +727,12 @@ def tune_fused_convs(model, example, reps=5, verbose=False, allow=None):
             torch.cuda.synchronize()
             times[impl] = e0.elapsed_time(e1) / reps
         best = min(times, key=times.get)
+        if best == 'miopen' and len(times) > 1:
+            # a library kernel has to win by more than the timing noise: within 2 % the hand-written form is kept
+            # (same speed, and its summation order -- hence its output -- does not depend on a find step)
+            own = min((k for k in times if k != 'miopen'), key=times.get)
+            if times[own] <= 1.02 * times['miopen']:
+                best = own
         m.impl, m.tuned = best, times
         m.release(best)
         report[name] = (best, {k: round(v, 4) for k, v in times.items()})
