@@ -736,3 +736,111 @@ def test_conv_bn_act_with_projection(hip, cfg):
     ref = torch.nn.functional.conv2d(y, pw.view(n, Cout, 1, 1), pb)
     bound = torch.nn.functional.conv2d(y.abs() + 1, pw.abs().view(n, Cout, 1, 1))
     assert torch.all((got.cpu() - ref).abs() <= 1e-5 * bound + 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ emp_tracks.hip
+def _random_run_table(rng, D, H, W, n_inst):
+    """a run table like emp_runs_extract / emp_runs_label produce (raster order, runs of a component share a slice),
+    with adjacent and row-wrapping runs so that the merge rule has work, plus components without an instance"""
+    r_start, r_len, r_comp, c_slice = [], [], [], []
+    for d in range(D):
+        for y in range(H):
+            x = 0
+            while x < W:
+                if rng.random() < 0.35:
+                    x += int(rng.integers(1, 6))
+                    continue
+                ln = int(min(W - x, rng.integers(1, 9)))
+                r_start.append(y * W + x)
+                r_len.append(ln)
+                r_comp.append(len(c_slice))
+                c_slice.append(d)
+                x += ln                                   # the next run may start right here: contiguous runs
+    n_comp = len(c_slice)
+    comp_inst = rng.integers(-1, n_inst, n_comp).astype(np.int32)
+    return (np.array(r_start, np.int32), np.array(r_len, np.int32), np.array(r_comp, np.int32),
+            np.array(c_slice, np.int32), comp_inst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('axis', ['xy', 'xz'])
+def test_track_lift_sort_offsets_expand_clip(axis):
+    from empanada_amd import _hip
+    from empanada_amd.inference import device_tracks as DT
+    from oracle import tracks as OT
+    rng = np.random.default_rng(5)
+    for D, H, W, n_inst in ((3, 4, 64, 3), (7, 9, 33, 12), (1, 1, 200, 2), (5, 6, 16, 4000)):
+        r_start, r_len, r_comp, c_slice, comp_inst = _random_run_table(rng, D, H, W, n_inst)
+        shape3d = (D + 2, H, W) if axis == 'xy' else (H, D + 2, W)
+        Z, Y, X = shape3d
+        t = _hip.RunTable()
+        t.D, t.H, t.W, t.n_runs, t.n_comp = D, H, W, len(r_start), len(c_slice)
+        dev = lambda a: torch.from_numpy(a).cuda()
+        t.r_start, t.r_len, t.r_comp, t.c_slice = dev(r_start), dev(r_len), dev(r_comp), dev(c_slice)
+        base = 7
+        key, st, ln, n = DT.lift_runs(t, comp_inst, axis, shape3d, slice0=2, inst_base=base)
+        ek, el = OT.lift_xy_xz(0 if axis == 'xy' else 1, r_start, r_len, r_comp, c_slice, comp_inst, H, W, Y, X, 2, base)
+        ek, el = OT.sort_runs(ek, el)
+        assert n == len(ek) and n > 0
+        np.testing.assert_array_equal(key[:n].cpu().numpy().view(np.uint64), ek)
+        np.testing.assert_array_equal(ln[:n].cpu().numpy(), el)
+        np.testing.assert_array_equal(st[:n].cpu().numpy(), (ek & np.uint64((1 << 40) - 1)).astype(np.int64))
+        # offsets / expand
+        top = base + n_inst
+        off = torch.empty((top + 1,), dtype=torch.int64, device='cuda')
+        _hip.call('emp_track_offsets', key.data_ptr(), n, top, off.data_ptr(), _hip.stream())
+        eo = OT.offsets(ek, top)
+        np.testing.assert_array_equal(off.cpu().numpy(), eo)
+        val = rng.integers(0, 100, top).astype(np.int32)
+        out = torch.empty((n,), dtype=torch.int32, device='cuda')
+        _hip.call('emp_track_expand', off.data_ptr(), dev(val).data_ptr(), top, n, out.data_ptr(), _hip.stream())
+        np.testing.assert_array_equal(out.cpu().numpy(), OT.expand(eo, val, n))
+        # clip to a slab
+        lo, hi = int(0.3 * Z * Y * X), int(0.7 * Z * Y * X)
+        ck, cl, cn = DT.clip_runs(key, ln, n, lo, hi)
+        xk, xl = OT.clip(ek, el, lo, hi)
+        assert cn == len(xk)
+        np.testing.assert_array_equal(ck[:cn].cpu().numpy().view(np.uint64), xk)
+        np.testing.assert_array_equal(cl[:cn].cpu().numpy(), xl)
+
+
+@pytest.mark.gpu
+def test_track_lift_yz_and_touch_merge():
+    from empanada_amd import _hip
+    from empanada_amd.inference import device_tracks as DT
+    from oracle import tracks as OT
+    rng = np.random.default_rng(9)
+    for Z, Y, Xl, X, x0 in ((3, 4, 8, 8, 0), (5, 6, 7, 20, 9), (2, 3, 16, 16, 0)):
+        # a yz stack: Xl slices of (Z, Y) pixels; instances drawn as boxes so that full rows occur (runs that touch
+        # across row ends must merge)
+        n_inst = 6
+        vol = np.zeros((Z, Y, Xl), dtype=np.int64)
+        for i in range(n_inst):
+            z0, y0, a0 = rng.integers(0, Z), rng.integers(0, Y), rng.integers(0, Xl)
+            vol[z0:z0 + rng.integers(1, 3), y0:y0 + rng.integers(1, 4), a0:] = i + 1
+        vol[0, :, :] = 1                                                   # whole rows: touch across row ends
+        stack = np.ascontiguousarray(np.moveaxis(vol, 2, 0))               # (Xl, Z, Y) slices
+        pan = torch.from_numpy((stack + (stack > 0) * 1000).astype(np.int32)).cuda().view(torch.uint32)
+        table = _hip.extract_runs(pan, 1000, [])                           # plain classes: one component per value
+        val = table.r_val.cpu().numpy()[table.c_first.cpu().numpy()].astype(np.int64)
+        comp_inst = (val - 1001).astype(np.int32)
+        key, st, ln, n = DT.lift_runs(table, comp_inst, 'yz', (Z, Y, X), slice0=x0, inst_base=3)
+        ek, el = OT.lift_yz(vol, X, x0, 3)
+        ek, el = OT.sort_runs(ek, el, merge_touching=True)
+        assert n == len(ek)
+        np.testing.assert_array_equal(key[:n].cpu().numpy().view(np.uint64), ek)
+        np.testing.assert_array_equal(ln[:n].cpu().numpy(), el)
+        assert int(ln[:n].sum().item()) == int((vol > 0).sum())
+
+
+@pytest.mark.gpu
+def test_triplets_reduce():
+    from empanada_amd import _hip
+    from oracle import tracks as OT
+    rng = np.random.default_rng(3)
+    for n in (1, 17, 5000, 200000):
+        trip = np.stack([rng.integers(0, 50, n), rng.integers(0, 60, n), rng.integers(1, 300, n)], axis=1).astype(np.int32)
+        got = _hip.reduce_triplets(torch.from_numpy(trip).cuda()).cpu().numpy().astype(np.int64)
+        np.testing.assert_array_equal(got, OT.reduce_triplets(trip))
+    empty = torch.zeros((0, 3), dtype=torch.int32, device='cuda')
+    assert _hip.reduce_triplets(empty).shape[0] == 0
