@@ -32,7 +32,7 @@ from .postprocess import centers_batched
 
 __all__ = ['shard_bounds', 'merge_rank_tables', 'filter_labels', 'gather_tables_and_chain', 'chain_over_ranks',
            'median_handover', 'sharded_panoptic_stack', 'sharded_tables', 'fill_slab', 'sharded_stack_volume',
-           'track_plane', 'finish_plane', 'gather_plane_runs', 'gather_plane_tracks', 'consensus_volume']
+           'track_plane', 'finish_plane', 'gather_plane_runs', 'gather_plane_tracks', 'consensus_volume', 'plane_volume']
 
 
 def _world(group=None):
@@ -437,3 +437,45 @@ def consensus_volume(planes, shape3d, labels, thing_list, pixel_vote_thr=2, clus
         cons[class_id] = res
         vols[class_id] = vol.reshape(z1 - z0, Y, X)
     return cons, vols, (z0, z1)
+
+
+def plane_volume(pt, labels, thing_list, min_size=None, min_span=None, group=None):
+    """Stack mode with per-class outputs (scripts/pdl_inference3d.py:222-233 with a single axis: the class's tracker IS
+    the result): size / span filters on the xy plane's trackers, then every class's instances painted with their own
+    labels into the rank's z-slab -- uint32 for thing classes; stuff classes as a uint8 mask (value 1; the reference
+    writes the label class * divisor into a uint8 array there, which does not fit).
+    Returns ({class: (z1 - z0, Y, X) device slab}, (z0, z1), {class: instances kept})."""
+    assert pt.axis == 'xy', "the slices of the xy plane are the z-slabs of the volume"
+    rank, world = _world(group)
+    Z, Y, X = pt.shape3d
+    zb = shard_bounds(Z, world)
+    z0, z1 = int(zb[rank]), int(zb[rank + 1])
+    if min_size is not None:
+        pt.remove_small_objects(min_size)
+    if min_span is not None:
+        pt.remove_pancakes(min_span)
+    dev = pt.ln.device
+    n = pt.n_runs
+    off = pt.offsets()
+    vols, counts = {}, {}
+    for c in labels:
+        keep = pt.alive & (pt.inst_cls == c)
+        counts[c] = int(keep.sum())
+        thing = c in thing_list
+        vol = torch.zeros(((z1 - z0) * Y * X,), dtype=torch.int32 if thing else torch.uint8, device=dev)
+        if n and keep.any():
+            st = (pt.st[:n] - z0 * Y * X).contiguous()
+            if thing:
+                order = torch.empty((n,), dtype=torch.int32, device=dev)
+                iota = torch.arange(pt.n_inst, dtype=torch.int32, device=dev)
+                _hip.call('emp_track_expand', _hip._ptr(off), _hip._ptr(iota), pt.n_inst, n, _hip._ptr(order), _hip.stream())
+                _hip.fill_runs_u32(vol.view(torch.uint32), st, pt.ln[:n].contiguous(), order,
+                                   _hip.np_to_dev_u32(np.where(keep, pt.inst_label, 0)))
+            else:
+                flag = torch.empty((n,), dtype=torch.int32, device=dev)
+                kd = torch.from_numpy(keep.astype(np.int32)).to(dev)
+                _hip.call('emp_track_expand', _hip._ptr(off), _hip._ptr(kd), pt.n_inst, n, _hip._ptr(flag), _hip.stream())
+                sel = flag > 0
+                _hip.fill_runs_u8(vol, st[sel].contiguous(), pt.ln[:n][sel].contiguous(), 1)
+        vols[c] = (vol.view(torch.uint32) if thing else vol).reshape(z1 - z0, Y, X)
+    return vols, (z0, z1), counts
