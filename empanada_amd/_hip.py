@@ -38,6 +38,9 @@ SIGNATURES = {
     'emp_upsample_bilinear': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     'emp_conv_bn_act_proj_nhwc': (_I, [_P, _P, _P, _P, _I] + [_I] * 10 + [_P, _I, _P, _P, _L, _P]),
     'emp_conv_k_slab': (_I, [_L, _I, _I, _I]),
+    'emp_conv_k_slab_cin': (_I, [_L, _I, _I, _I, _I]),
+    'emp_gconv_chunk': (_I, [_I]),
+    'emp_gconv3x3_bn_act_nhwc': (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     'emp_conv_bn_act_nhwc': (_I, [_P, _P, _P, _P, _P, _L, _I] + [_I] * 10 + [_P, _L, _P]),
     'emp_wino_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     'emp_gemm_nt_batched': (_I, [_P, _P, _I, _L, _I, _I, _P, _P]),
@@ -520,7 +523,8 @@ def upsample_bilinear(x, size, out=None):
 def conv_bn_act_nhwc(x, w_okkc, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, dil=1, out=None):
     """Fused convolution + per-channel affine + residual + ReLU on the fp32 matrix cores (emp_conv_bn_act_nhwc).
     x: (N,Cin,H,W) fp32 channels_last; w_okkc: (Cout,KH,KW,Cin) contiguous; residual: (N,Cout,OH,OW) channels_last
-    (or a channel slice); out: optional (N,Cout,OH,OW) channel slice of a channels_last buffer."""
+    (or a channel slice); out: optional (N,Cout,OH,OW) channel slice of a channels_last buffer.
+    relu='gate': the squeeze-excite epilogue, out = residual * sigmoid(acc * scale + shift)."""
     require_gpu()
     N, Cin, H, W = x.shape
     Cout, KH, KW, _ = w_okkc.shape
@@ -539,10 +543,32 @@ def conv_bn_act_nhwc(x, w_okkc, scale=None, shift=None, residual=None, relu=Fals
     ops = pixel_stride(out)
     rps = pixel_stride(residual) if residual is not None else 0
     call('emp_conv_bn_act_nhwc', x.data_ptr(), _ptr(w_okkc), _ptr(scale), _ptr(shift),
-         residual.data_ptr() if residual is not None else None, rps, int(bool(relu)), N, H, W, Cin, Cout, KH, KW,
+         residual.data_ptr() if residual is not None else None, rps, 2 if relu == 'gate' else int(bool(relu)),
+         N, H, W, Cin, Cout, KH, KW,
          stride, pad, dil, out.data_ptr(), ops, stream(),
          alg_bytes=4 * (x.numel() + w_okkc.numel() + N * Cout * OH * OW * (2 if residual is not None else 1)),
          alg_flops=2 * N * OH * OW * Cout * Cin * KH * KW)
+    return out
+
+
+def gconv3x3_bn_act_nhwc(x, w_okkc, groups, scale=None, shift=None, relu=False, stride=1, out=None):
+    """Grouped 3x3 convolution (padding 1, stride 1 / 2) + per-channel affine + ReLU on the fp32 matrix cores
+    (emp_gconv3x3_bn_act_nhwc).  x: (N,C,H,W) fp32 channels_last; w_okkc: (C,3,3,C/groups) contiguous."""
+    require_gpu()
+    N, C, H, W = x.shape
+    GW = C // groups
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    assert tuple(w_okkc.shape) == (C, 3, 3, GW) and w_okkc.is_contiguous() and GW * groups == C
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((N, C, OH, OW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    assert out.shape == (N, C, OH, OW) and out.stride(1) == 1
+    ops = out.stride(3)
+    assert out.stride(2) == OW * ops and out.stride(0) == OH * OW * ops, "NHWC channel slice required"
+    call('emp_gconv3x3_bn_act_nhwc', x.data_ptr(), C, _ptr(w_okkc), _ptr(scale), _ptr(shift), int(bool(relu)),
+         N, H, W, groups, GW, stride, out.data_ptr(), ops, stream(),
+         alg_bytes=4 * (x.numel() + w_okkc.numel() + N * C * OH * OW),
+         alg_flops=2 * N * OH * OW * C * GW * 9)
     return out
 
 
@@ -683,9 +709,11 @@ def wino4_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, 
     return out
 
 
-def conv_k_slab(M, Cout, batch=1, has_residual=False):
+def conv_k_slab(M, Cout, batch=1, has_residual=False, Cin=None):
     """K-slab (16 or 32) emp_conv_bn_act_nhwc / emp_gemm_nt_batched use for an (M x Cout) output, `batch` GEMMs per
     launch: fixes the summation order the oracle mirrors"""
+    if Cin is not None:
+        return int(load().emp_conv_k_slab_cin(int(M), int(Cout), int(batch), int(bool(has_residual)), int(Cin)))
     return int(load().emp_conv_k_slab(int(M), int(Cout), int(batch), int(bool(has_residual))))
 
 

@@ -476,8 +476,12 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
                 for (int e = 0; e < 4; ++e) {
                     if (g.scale) v[e] = __fmul_rn(v[e], sc[e]);
                     if (g.shift) v[e] = __fadd_rn(v[e], sh[e]);
-                    if (g.res) v[e] = __fadd_rn(v[e], rr[e]);
-                    if (g.relu) v[e] = fmaxf(v[e], 0.f);
+                    if (g.relu == 2) {                      // squeeze-excite gate: res * sigmoid(v)
+                        v[e] = __fmul_rn(rr[e], __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v[e]))));
+                    } else {
+                        if (g.res) v[e] = __fadd_rn(v[e], rr[e]);
+                        if (g.relu) v[e] = fmaxf(v[e], 0.f);
+                    }
                 }
                 if (!PROJ || g.out) {
                     if (vec_ok) {
@@ -531,7 +535,7 @@ struct CgPlan {
     int slab, tiles_m, tiles_n;
 };
 
-static CgPlan cg_plan(int64_t M, int Cout, int batch, bool has_res, bool res_vec_ok, bool may_split_n = true)
+static CgPlan cg_plan(int64_t M, int Cout, int batch, bool has_res, bool res_vec_ok, bool may_split_n = true, int cin = 32)
 {
     CgPlan p;
     // 64-wide cout tiles for narrow layers, and whenever 128-wide tiles would leave CUs without a block (small
@@ -548,6 +552,10 @@ static CgPlan cg_plan(int64_t M, int Cout, int batch, bool has_res, bool res_vec
     if (force && force[0] == '1') p.slab = 16;
     if (force && force[0] == '3') p.slab = 32;
     if (p.respf) p.slab = 32;
+    if (cin % 32 != 0) {                 // Cin a multiple of 16 only (RegNet widths 144, 1296): 16-wide slabs throughout
+        p.slab = 16;
+        p.respf = false;
+    }
     static const char *noglds = getenv("EMP_CONV_NO_GLDS");          // experiments only
     p.glds = !noglds;
     return p;
@@ -558,6 +566,11 @@ extern "C" int emp_conv_k_slab(int64_t M, int Cout, int batch, int has_residual)
     return cg_plan(M, Cout, batch, has_residual != 0, true).slab;
 }
 
+extern "C" int emp_conv_k_slab_cin(int64_t M, int Cout, int batch, int has_residual, int Cin)
+{
+    return cg_plan(M, Cout, batch, has_residual != 0, true, true, Cin).slab;
+}
+
 extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
                                     const float *residual, int64_t res_pixel_stride, int relu, int N, int H, int W,
                                     int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float *out,
@@ -565,7 +578,8 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
 {
     EMP_REQUIRE(x && w_okkc && out, "conv: null pointer");
     EMP_REQUIRE(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv: bad shape");
-    EMP_REQUIRE(Cin % CG_BK == 0, "conv: Cin %d must be a multiple of %d", Cin, CG_BK);
+    EMP_REQUIRE(Cin % 16 == 0, "conv: Cin %d must be a multiple of 16", Cin);
+    EMP_REQUIRE(relu != 2 || residual, "conv: the gate epilogue (relu == 2) needs the gated tensor as residual");
     EMP_REQUIRE(KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7 && stride >= 1 && dil >= 1 && pad >= 0, "conv: bad filter geometry");
     const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
     const int OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
@@ -584,7 +598,7 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     g.M = (int64_t)N * OH * OW; g.out_ps = out_pixel_stride; g.res_ps = res_pixel_stride;
     g.x_bs = g.w_bs = g.out_bs = 0; g.tiles = nullptr; g.proj_w = nullptr; g.proj_out = nullptr; g.proj_n = 0; g.hw = 1;
     const bool res_vec_ok = (res_pixel_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
-    const CgPlan pl = cg_plan(g.M, Cout, 1, residual != nullptr, res_vec_ok);
+    const CgPlan pl = cg_plan(g.M, Cout, 1, residual != nullptr, res_vec_ok, true, Cin);
     const bool narrow = pl.narrow, respf = pl.respf, bk16 = pl.slab == 16;
     EMP_REQUIRE((int64_t)pl.tiles_m * pl.tiles_n < (1LL << 28), "conv: too many tiles");
     g.tiles_m = pl.tiles_m;

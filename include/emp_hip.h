@@ -102,10 +102,16 @@ int emp_upsample_bilinear(const float *x, int N, int C, int h, int w, const int6
  * Cout, 1, residual != NULL): 16 (three resident blocks per CU) when the launch has more than 512 blocks and does
  * not use the residual-prefetch variant, else 32.  The epilogue's multiply and adds are separate
  * fp32 roundings, as in emp_bn_act_nhwc.
- * x: (N, H, W, Cin), Cin % 32 == 0; w_okkc: (Cout, KH, KW, Cin) (the Conv2d weight permuted); residual and out
+ * x: (N, H, W, Cin), Cin % 16 == 0; w_okkc: (Cout, KH, KW, Cin) (the Conv2d weight permuted); residual and out
  * are addressed as base + pixel * pixel_stride + co (stride 0 means Cout), so out may be a channel slice of a
  * wider NHWC concat buffer.  x and w 16-byte aligned; out must not alias x.                                    */
 int emp_conv_k_slab(int64_t M, int Cout, int batch, int has_residual);
+/* the same for a given Cin: Cin % 32 != 0 (RegNet widths 144, 1296: multiples of 16 only) always takes S = 16 */
+int emp_conv_k_slab_cin(int64_t M, int Cout, int batch, int has_residual, int Cin);
+/* relu == 2 selects the squeeze-excite gate epilogue (SqueezeExcite.forward, empanada/models/blocks.py:35-50:
+ * x * sigmoid(conv(s) + bias)): out = residual * (1 / (1 + expf(-(acc * scale + shift)))), residual = the gated
+ * tensor x (required); the division and the product are separate fp32 roundings, expf is the device library's.
+ * Cin % 16 == 0 (round 2; was 32).                                                                            */
 int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
                          const float *residual, int64_t res_pixel_stride, int relu, int N, int H, int W,
                          int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float *out,
@@ -122,6 +128,23 @@ int emp_conv_bn_act_proj_nhwc(const float *x, const float *w_okkc, const float *
                               int relu, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                               int pad, int dil, const float *proj_w, int proj_n, float *proj_out,
                               float *out, int64_t out_pixel_stride, void *stream);
+
+/* ---- D8: grouped 3x3 convolution + BatchNorm(eval) + ReLU, NHWC fp32, fp32 matrix cores (16x16x4 tiles) -----
+ * replaces Conv2d(w, w, 3, stride, padding=1, groups=w/group_w) -> BatchNorm2d -> ReLU of the RegNet bottleneck
+ *          Bottleneck.__init__ / forward              empanada/models/encoders/regnet.py:59-71,88-104
+ *          conv_bn_act(groups=...)                    empanada/models/blocks.py:121-171
+ * out[p, co] = act(acc * scale[co] + shift[co]), co = grp * group_w + j; acc = sum over the 9 taps and the group's
+ * group_w input channels of x[n, oy*stride - 1 + ky, ox*stride - 1 + kx, grp*group_w + c] * w_okkc[co, ky, kx, c],
+ * evaluated as ONE fp32 fma chain from +0: taps in raster order; per tap chunks of CK = emp_gconv_chunk(group_w)
+ * channels ascending (24, 16 or 8: the largest that divides group_w); per chunk 8-channel slabs j ascending; per
+ * slab e = 0, 1; per e the channels 8j + 2kq + e, kq = 0..3 (one v_mfma_f32_16x16x4_f32 = an fmaf chain over its four
+ * k's).  Taps outside the image enter as x = 0.  group_w: a multiple of 8 in 8..128; stride 1 or 2.
+ * x: base + pixel * x_pixel_stride + channel (0 means groups * group_w), w_okkc: (groups * group_w, 3, 3, group_w) =
+ * the Conv2d weight permuted; out likewise with out_pixel_stride.  x, w, out 16-byte aligned, strides % 4 == 0. */
+int emp_gconv_chunk(int group_w);
+int emp_gconv3x3_bn_act_nhwc(const float *x, int64_t x_pixel_stride, const float *w_okkc, const float *scale,
+                             const float *shift, int relu, int N, int H, int W, int groups, int group_w,
+                             int stride, float *out, int64_t out_pixel_stride, void *stream);
 
 /* ---- D5: Winograd F(2x2, 3x3) convolution in three calls (3x3, stride 1, padding == dilation) ---------
  * replaces the dilated 3x3 Conv2d -> BatchNorm2d -> ReLU of ASPP and of the dilated ResNet stage

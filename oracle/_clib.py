@@ -46,5 +46,7 @@ def lib():
         L.emp_oracle_dwconv_nhwc.argtypes = [f32p, f32p, f32p] + [ctypes.c_int] * 5 + [f32p]
         L.emp_oracle_conv_bn_act_nhwc.restype = None
         L.emp_oracle_conv_bn_act_nhwc.argtypes = [f32p] * 5 + [ctypes.c_int] * 12 + [f32p]
+        L.emp_oracle_gconv3x3_bn_act_nhwc.restype = None
+        L.emp_oracle_gconv3x3_bn_act_nhwc.argtypes = [f32p] * 4 + [ctypes.c_int] * 8 + [f32p]
         _lib = L
     return _lib

@@ -248,9 +248,52 @@ void emp_oracle_conv_bn_act_nhwc(const float *x, const float *w, const float *sc
                     float v = acc;
                     if (scale) v = v * scale[co];
                     if (shift) v = v + shift[co];
-                    if (res) v = v + res[p * Cout + co];
-                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    if (relu == 2) {                 /* squeeze-excite gate (blocks.py:35-50): x * sigmoid(conv(s) + b) */
+                        v = res[p * Cout + co] * (1.0f / (1.0f + expf(-v)));
+                    } else {
+                        if (res) v = v + res[p * Cout + co];
+                        if (relu) v = v > 0.0f ? v : 0.0f;
+                    }
                     out[p * Cout + co] = v;
+                }
+            }
+}
+
+/* D8 (emp_gconv3x3_bn_act_nhwc): grouped 3x3 convolution, padding 1, stride 1 or 2, NHWC, G groups of GW channels
+ * (Conv2d(w, w, 3, stride, 1, groups=G) of the RegNet bottleneck, empanada/models/encoders/regnet.py:59-71) + affine +
+ * ReLU.  w: (G*GW, 3, 3, GW).  One fmaf chain from +0 per output: taps in raster order; per tap chunks of CK channels
+ * ascending (CK = emp_gconv_chunk(GW): 24, 16 or 8); per chunk 8-channel slabs j ascending; per slab e = 0, 1; per e
+ * the channels 8j + 2kq + e for kq = 0..3.  Taps outside the image enter as x = 0. */
+void emp_oracle_gconv3x3_bn_act_nhwc(const float *x, const float *w, const float *scale, const float *shift, int relu,
+                                     int N, int H, int W, int G, int GW, int stride, int CK, float *out)
+{
+    const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+    const int C = G * GW;
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox) {
+                const int64_t p = ((int64_t)n * OH + oy) * OW + ox;
+                for (int co = 0; co < C; ++co) {
+                    const int grp = co / GW;
+                    float acc = 0.0f;
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int iy = oy * stride - 1 + tap / 3, ix = ox * stride - 1 + tap % 3;
+                        const int in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                        const float *xp = in ? x + (((int64_t)n * H + iy) * W + ix) * C + grp * GW : 0;
+                        const float *wp = w + ((int64_t)co * 9 + tap) * GW;
+                        for (int c0 = 0; c0 < GW; c0 += CK)
+                            for (int j = 0; j < CK / 8; ++j)
+                                for (int e = 0; e < 2; ++e)
+                                    for (int kq = 0; kq < 4; ++kq) {
+                                        const int c = c0 + 8 * j + 2 * kq + e;
+                                        acc = fmaf(in ? xp[c] : 0.0f, wp[c], acc);
+                                    }
+                    }
+                    float v = acc;
+                    if (scale) v = v * scale[co];
+                    if (shift) v = v + shift[co];
+                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    out[p * C + co] = v;
                 }
             }
 }

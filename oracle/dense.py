@@ -78,9 +78,37 @@ def conv_bn_act_nhwc(x_nhwc, w_okkc, scale=None, shift=None, residual=None, relu
         return a, a.ctypes.data_as(f32p)
 
     keep = [ptr(a) for a in (scale, shift, residual)]
+    act = 2 if relu == 'gate' else int(bool(relu))       # 'gate': y = residual * sigmoid(acc * scale + shift)
     lib().emp_oracle_conv_bn_act_nhwc(x.ctypes.data_as(f32p), w.ctypes.data_as(f32p), keep[0][1], keep[1][1],
-                                      keep[2][1], int(bool(relu)), N, H, W, Cin, Cout, KH, KW, stride, pad, dil,
+                                      keep[2][1], act, N, H, W, Cin, Cout, KH, KW, stride, pad, dil,
                                       int(slab), y.ctypes.data_as(f32p))
+    return y
+
+
+def gconv_chunk(group_w):
+    """channels per K chunk of the grouped kernel (emp_gconv_chunk)"""
+    return 24 if group_w % 24 == 0 else 16 if group_w % 16 == 0 else 8
+
+
+def gconv3x3_bn_act_nhwc(x_nhwc, w_okkc, groups, scale=None, shift=None, relu=False, stride=1):
+    """Grouped 3x3 convolution (padding 1) + affine + ReLU: x (N,H,W,C), w (C,3,3,C/groups), summation order of
+    include/emp_hip.h (D8).  Restates the grouped Conv2d + BatchNorm2d + ReLU of the RegNet bottleneck
+    (empanada/models/encoders/regnet.py:59-71, blocks.py:121-171); pinned against torch's conv2d(groups=G) within
+    fp32 rounding in tests/test_oracle_dense.py.  Plain C (oracle/c/oracle_kernels.c)."""
+    x = np.ascontiguousarray(x_nhwc, dtype=np.float32)
+    w = np.ascontiguousarray(w_okkc, dtype=np.float32)
+    N, H, W, C = x.shape
+    GW = C // groups
+    assert w.shape == (C, 3, 3, GW) and GW * groups == C and GW % 8 == 0
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = np.empty((N, OH, OW, C), dtype=np.float32)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
+    lib().emp_oracle_gconv3x3_bn_act_nhwc(x.ctypes.data_as(f32p), w.ctypes.data_as(f32p),
+                                          None if sc is None else sc.ctypes.data_as(f32p),
+                                          None if sh is None else sh.ctypes.data_as(f32p), int(bool(relu)),
+                                          N, H, W, groups, GW, stride, gconv_chunk(GW), y.ctypes.data_as(f32p))
     return y
 
 

@@ -543,6 +543,98 @@ def test_conv_bn_act_nhwc(hip, cfg):
     assert torch.equal(buf[:, 8:], got) and torch.all(buf[:, :8] == 5.0)
 
 
+@pytest.mark.parametrize('cfg', [
+    (2, 9, 11, 2, 72, 1, True),        # RegNetY-6.4GF stage 1: 2 groups of 72, chunks of 24 channels
+    (1, 16, 16, 4, 72, 2, True),       # stride 2 (first block of a stage)
+    (3, 7, 5, 18, 72, 1, False),       # 18 groups (stage 4 width 1296), no ReLU
+    (2, 12, 10, 3, 56, 1, True),       # RegNetY-8GF group width: chunks of 8
+    (1, 9, 9, 2, 112, 2, True),        # RegNetY-16GF: chunks of 16, 7 cout tiles
+    (1, 20, 20, 5, 8, 1, True),        # narrowest group
+    (1, 6, 6, 1, 128, 1, True),        # widest group (8 cout tiles)
+    (4, 64, 64, 8, 72, 1, True),       # 1024 blocks: every XCD slot used several times over
+])
+def test_gconv3x3_bn_act_nhwc(hip, cfg):
+    """emp_gconv3x3_bn_act_nhwc (D8): bit-exact against the C oracle (same fma chain over 16x16x4 MFMAs); within
+    fp32 rounding of torch's conv2d(groups=G) + affine + relu, |err| <= 2e-6 * sum|x||w| * |scale| + 1e-6; output
+    into a channel slice of a wider NHWC buffer leaves the other channels untouched."""
+    from oracle import dense as OD
+    N, H, W, G, GW, stride, relu = cfg
+    C = G * GW
+    g = torch.Generator().manual_seed(C * 3 + H + stride)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, GW, 3, 3, generator=g) * (1.0 / (GW * 9) ** 0.5)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    w_okkc = w.permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    got = hip.gconv3x3_bn_act_nhwc(xd, w_okkc.cuda(), G, sc.cuda(), sh.cuda(), relu, stride)
+    exp = OD.gconv3x3_bn_act_nhwc(x.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), G, sc.numpy(), sh.numpy(), relu, stride)
+    assert OD.gconv_chunk(GW) == hip.load().emp_gconv_chunk(GW)
+    np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    ref = torch.nn.functional.conv2d(x, w, None, stride=stride, padding=1, groups=G)
+    bound = torch.nn.functional.conv2d(x.abs(), w.abs(), None, stride=stride, padding=1, groups=G) * sc.view(1, -1, 1, 1)
+    y = ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if relu:
+        y = torch.relu(y)
+    assert torch.all((got.cpu() - y).abs() <= 2e-6 * bound + 1e-6)
+    buf = torch.full((N, C + 8, ref.shape[2], ref.shape[3]), 5.0, device='cuda').contiguous(memory_format=torch.channels_last)
+    hip.gconv3x3_bn_act_nhwc(xd, w_okkc.cuda(), G, sc.cuda(), sh.cuda(), relu, stride, out=buf[:, 8:])
+    assert torch.equal(buf[:, 8:], got) and torch.all(buf[:, :8] == 5.0)
+    # no epilogue operands
+    got0 = hip.gconv3x3_bn_act_nhwc(xd, w_okkc.cuda(), G, None, None, False, stride)
+    exp0 = OD.gconv3x3_bn_act_nhwc(x.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), G, None, None, False, stride)
+    np.testing.assert_array_equal(got0.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp0.view(np.uint32))
+
+
+@pytest.mark.parametrize('cfg', [
+    (2, 16, 16, 144, 144, False, True),      # RegNetY widths: Cin a multiple of 16 only -> 16-wide K-slabs
+    (2, 16, 16, 144, 144, True, True),       # with the shortcut (no residual prefetch on this path)
+    (1, 8, 8, 1296, 1296, True, True),
+    (8, 64, 64, 144, 48, False, True),       # squeeze conv, Cout padded 36 -> 48 by the host
+    (1, 12, 12, 48, 144, False, False),
+])
+def test_conv_cin_multiple_of_16(hip, cfg):
+    """emp_conv_bn_act_nhwc with Cin % 32 != 0: bit-exact against the oracle at S = emp_conv_k_slab_cin(..) == 16."""
+    from oracle import dense as OD
+    N, H, W, Cin, Cout, use_res, relu = cfg
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (1.0 / Cin ** 0.5)
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    res = torch.randn(N, Cout, H, W, generator=g) if use_res else None
+    w_okkc = w.permute(0, 2, 3, 1).contiguous()
+    slab = hip.conv_k_slab(N * H * W, Cout, 1, use_res, Cin)
+    assert slab == 16
+    got = hip.conv_bn_act_nhwc(x.cuda().contiguous(memory_format=torch.channels_last), w_okkc.cuda(), sc.cuda(), sh.cuda(),
+                               res.cuda().contiguous(memory_format=torch.channels_last) if use_res else None, relu)
+    exp = OD.conv_bn_act_nhwc(x.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), sc.numpy(), sh.numpy(),
+                              res.permute(0, 2, 3, 1).numpy() if use_res else None, relu, slab=slab)
+    np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
+@pytest.mark.parametrize('cfg', [(2, 16, 16, 48, 144), (1, 8, 8, 80, 288), (8, 64, 64, 144, 576), (1, 4, 4, 336, 1296)])
+def test_conv_gate_epilogue(hip, cfg):
+    """relu == 2 (squeeze-excite gate, blocks.py:35-50): out = x * sigmoid(conv(s) + b).  The accumulator is
+    bit-exact (same kernel); expf is the device library's, so the gate is compared with the oracle (glibc expf) and
+    with torch's CPU sigmoid within a few ulp of the result: |err| <= 5e-7 * |x|."""
+    from oracle import dense as OD
+    N, H, W, Cin, Cout = cfg
+    g = torch.Generator().manual_seed(Cin + Cout)
+    s_in = torch.relu(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    x = torch.randn(N, Cout, H, W, generator=g) * 3
+    w_okkc = w.permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    got = hip.conv_bn_act_nhwc(s_in.cuda().contiguous(memory_format=torch.channels_last), w_okkc.cuda(), None, b.cuda(),
+                               xd, 'gate').cpu()
+    slab = hip.conv_k_slab(N * H * W, Cout, 1, True, Cin)
+    exp = torch.from_numpy(OD.conv_bn_act_nhwc(s_in.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), None, b.numpy(),
+                                               x.permute(0, 2, 3, 1).numpy(), 'gate', slab=slab)).permute(0, 3, 1, 2)
+    assert torch.all((got - exp).abs() <= 5e-7 * x.abs())
+    ref = x * torch.sigmoid(torch.nn.functional.conv2d(s_in, w, b))
+    assert torch.all((got - ref).abs() <= 2e-5 * x.abs())      # conv rounding (K up to 336) inside the sigmoid's slope <= 1/4
+
+
 @pytest.mark.parametrize('cfg', [(2, 9, 11, 64, 128, 1), (1, 12, 10, 32, 40, 2), (2, 13, 8, 64, 132, 6),
                                  (1, 5, 7, 96, 64, 4), (3, 16, 16, 32, 256, 3)])
 def test_winograd_conv(hip, cfg):

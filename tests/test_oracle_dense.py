@@ -76,3 +76,36 @@ def test_projection_oracle_vs_torch():
     y = torch.relu(F.conv2d(x, w) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     ref = F.conv2d(y, pw.view(2, 128, 1, 1), pb).numpy()
     assert np.abs(got - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize('cfg', [(2, 9, 11, 2, 72, 1), (1, 8, 8, 4, 72, 2), (2, 7, 5, 3, 56, 1), (1, 9, 9, 2, 112, 2),
+                                 (1, 6, 6, 2, 16, 1)])
+def test_gconv_oracle_vs_torch(cfg):
+    """oracle.dense.gconv3x3_bn_act_nhwc (the order emp_gconv3x3_bn_act_nhwc documents) against the library call the
+    reference makes -- Conv2d(groups=G) + BatchNorm2d(eval) + ReLU (encoders/regnet.py:59-71) -- in float64:
+    |err| <= 2e-6 * sum|x||w| * |scale| + 1e-6."""
+    N, H, W, G, GW, stride = cfg
+    C = G * GW
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, GW, 3, 3, generator=g) * (1.0 / (GW * 9) ** 0.5)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    got = torch.from_numpy(OD.gconv3x3_bn_act_nhwc(_nhwc(x), w.permute(0, 2, 3, 1).contiguous().numpy(),
+                                                   G, sc.numpy(), sh.numpy(), True, stride)).permute(0, 3, 1, 2)
+    ref = F.conv2d(x.double(), w.double(), None, stride=stride, padding=1, groups=G)
+    ref = torch.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    bound = F.conv2d(x.abs(), w.abs(), None, stride=stride, padding=1, groups=G) * sc.view(1, -1, 1, 1)
+    assert torch.all((got.double() - ref).abs() <= 2e-6 * bound + 1e-6)
+
+
+def test_gate_oracle_vs_torch():
+    """oracle conv with the squeeze-excite gate epilogue against x * sigmoid(conv1x1(s) + b) (blocks.py:35-50)."""
+    g = torch.Generator().manual_seed(5)
+    s_in = torch.relu(torch.randn(2, 48, 6, 7, generator=g))
+    w = torch.randn(144, 48, 1, 1, generator=g) * 0.2
+    b = torch.randn(144, generator=g)
+    x = torch.randn(2, 144, 6, 7, generator=g)
+    got = torch.from_numpy(OD.conv_bn_act_nhwc(_nhwc(s_in), w.permute(0, 2, 3, 1).contiguous().numpy(),
+                                               None, b.numpy(), _nhwc(x), 'gate', slab=16)).permute(0, 3, 1, 2)
+    ref = x.double() * torch.sigmoid(F.conv2d(s_in.double(), w.double(), b.double()))
+    assert torch.all((got.double() - ref).abs() <= 2e-6 * x.abs() + 1e-7)
