@@ -18,9 +18,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .panoptic_deeplab import (PanopticDeepLabHead, PointRendSemSegHead, SeparableConv2d, _RESNETS, _conv_bn_act,
-                               _up_bilinear,
-                               resnet_encoder)
+from .panoptic_deeplab import (FusedConvBNAct, PanopticDeepLabHead, PointRendSemSegHead, SeparableConv2d, _RESNETS,
+                               _conv_bn_act, _no_late_weights, _up_bilinear, resnet_encoder)
 
 __all__ = ['PanopticBiFPN', 'PanopticBiFPNPR', 'regnet_encoder', 'REGNETS']
 
@@ -74,6 +73,42 @@ class SqueezeExcite(nn.Module):
         return x * self.se(self.avg_pool(x))
 
 
+class FusedSqueezeExcite(nn.Module):
+    """Inference-only stand-in for SqueezeExcite on NHWC fp32 activations: two launches of the fused convolution
+    kernel.  s = relu(W1 x + b1) (emp_conv_bn_act_nhwc, the squeeze width padded to a multiple of 16 with zero filters
+    and zero bias, so the padding channels are exact zeros), then out = x * sigmoid(W2 s + b2) in the second launch's
+    epilogue (relu == 2): the gate tensor, the sigmoid pass and the multiply pass never touch memory."""
+
+    def __init__(self, se):
+        super().__init__()
+        c1, c2 = se.se[0], se.se[2]
+        ns, nin = c1.out_channels, c1.in_channels
+        nsp = -(-ns // 16) * 16
+        w1 = torch.zeros(nsp, 1, 1, nin, dtype=torch.float32, device=c1.weight.device)
+        w1[:ns] = c1.weight.detach().float().permute(0, 2, 3, 1)
+        b1 = torch.zeros(nsp, dtype=torch.float32, device=c1.weight.device)
+        b1[:ns] = c1.bias.detach().float()
+        w2 = torch.zeros(nin, 1, 1, nsp, dtype=torch.float32, device=c1.weight.device)
+        w2[..., :ns] = c2.weight.detach().float().permute(0, 2, 3, 1)
+        for name, t in (('w1', w1), ('b1', b1), ('w2', w2), ('b2', c2.bias.detach().float().clone())):
+            self.register_buffer(name, t.contiguous(), persistent=False)
+        self._register_load_state_dict_pre_hook(_no_late_weights)
+
+    @staticmethod
+    def eligible(se):
+        return (isinstance(se, SqueezeExcite) and se.se[0].in_channels % 16 == 0 and se.se[0].bias is not None
+                and se.se[2].bias is not None and se.se[0].weight.dtype == torch.float32)
+
+    def forward(self, x):
+        from .. import _hip
+        if not (x.is_cuda and x.dtype == torch.float32):
+            raise RuntimeError("FusedSqueezeExcite needs fp32 CUDA activations")
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        s = _hip.conv_bn_act_nhwc(x, self.w1, None, self.b1, None, True)
+        return _hip.conv_bn_act_nhwc(s, self.w2, None, self.b2, x, 'gate')
+
+
 class Resample2d(nn.Module):
     """1x1 conv + BN when channels or stride change, identity otherwise (blocks.py:55-75)"""
 
@@ -108,8 +143,25 @@ class _RegBlock(nn.Module):
         self.bottleneck = _RegBottleneck(w_in, w_out, groups, stride, use_se)
         self.downsample = Resample2d(w_in, w_out, stride=stride)
         self.act = nn.ReLU(inplace=True)
+        self.fused_tail = False
+
+    def fuse_for_inference(self):
+        """After pair_conv_bn: the block's shortcut add + ReLU move into the epilogue of the last 1x1 convolution
+        (residual operand of FusedConvBNAct) and the squeeze-excite becomes FusedSqueezeExcite."""
+        b = self.bottleneck
+        if isinstance(b.c[0], FusedConvBNAct) and not self.fused_tail:
+            b.c[0].bn.relu = True
+            self.fused_tail = True
+            if b.use_se and FusedSqueezeExcite.eligible(b.se):
+                b.se = FusedSqueezeExcite(b.se)
 
     def forward(self, x):
+        if self.fused_tail:
+            b = self.bottleneck
+            y = b.b(b.a(x))
+            if b.use_se:
+                y = b.se(y)
+            return b.c[0](y, self.downsample(x))
         return self.act(self.downsample(x) + self.bottleneck(x))
 
 

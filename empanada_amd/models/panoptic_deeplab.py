@@ -149,6 +149,8 @@ class FusedConvBNAct(nn.Module):
       'wino3'  : Winograd F(3x3,3x3), 25 GEMMs (for sub-grids of 5-6 rows: the dilation-6 ASPP branch)
       'wino_sep': the same with V materialised -- emp_wino_input_transform / emp_gemm_nt_batched /
                  emp_wino_output_transform (less L2 traffic per matrix-core FLOP; wins when Cin is large)
+      'grouped': emp_gconv3x3_bn_act_nhwc -- the grouped 3x3 convolution of the RegNet bottleneck (one group per block,
+                 16x16x4 matrix-core tiles cut to the group width)
     tune_fused_convs() times the candidates on the layer's real shape and keeps the fastest."""
 
     def __init__(self, conv, bn):
@@ -166,19 +168,23 @@ class FusedConvBNAct(nn.Module):
     def candidates(self, has_residual):
         c = self.conv
         out = ['miopen']
-        plain = (c.groups == 1 and c.bias is None and c.padding_mode == 'zeros' and c.in_channels % 32 == 0
-                 and c.kernel_size[0] == c.kernel_size[1] and c.stride[0] == c.stride[1]
-                 and c.padding[0] == c.padding[1] and c.dilation[0] == c.dilation[1] and c.weight.dtype == torch.float32)
-        if plain:
+        square = (c.bias is None and c.padding_mode == 'zeros' and c.kernel_size[0] == c.kernel_size[1]
+                  and c.stride[0] == c.stride[1] and c.padding[0] == c.padding[1] and c.dilation[0] == c.dilation[1]
+                  and c.weight.dtype == torch.float32)
+        if square and c.groups == 1 and c.in_channels % 16 == 0:
             out.append('direct')
             if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == c.dilation and c.out_channels % 4 == 0
-                    and not has_residual):
+                    and c.in_channels % 32 == 0 and not has_residual):
                 out.extend(['wino', 'wino_sep', 'wino4', 'wino3'])
+        gw = c.in_channels // c.groups
+        if (square and c.groups > 1 and c.in_channels == c.out_channels and c.kernel_size == (3, 3) and c.padding == (1, 1)
+                and c.dilation == (1, 1) and c.stride[0] in (1, 2) and gw % 8 == 0 and 8 <= gw <= 128 and not has_residual):
+            out.append('grouped')
         return out
 
     def _prepare(self, impl):
         from .. import _hip
-        if impl == 'direct' and self._w_okkc is None:
+        if impl in ('direct', 'grouped') and self._w_okkc is None:
             self._w_okkc = self.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
         if impl in ('wino', 'wino_sep') and self._U is None:
             self._U = _hip.wino_filter_transform(self.conv.weight.detach())
@@ -188,7 +194,7 @@ class FusedConvBNAct(nn.Module):
             self._U3 = _hip.wino3_filter_transform(self.conv.weight.detach()).to(self.conv.weight.device)
 
     def release(self, keep):
-        if keep != 'direct':
+        if keep not in ('direct', 'grouped'):
             self._w_okkc = None
         if keep not in ('wino', 'wino_sep'):
             self._U = None
@@ -215,6 +221,9 @@ class FusedConvBNAct(nn.Module):
             return _hip.conv_bn_act_nhwc(x, self._w_okkc, self.bn.scale, self.bn.shift, residual, self.bn.relu,
                                          c.stride[0], c.padding[0], c.dilation[0], out)
         assert residual is None
+        if impl == 'grouped':
+            return _hip.gconv3x3_bn_act_nhwc(x, self._w_okkc, c.groups, self.bn.scale, self.bn.shift, self.bn.relu,
+                                             c.stride[0], out)
         m = {'wino4': 4, 'wino3': 3}.get(impl, 2)
         key = (x.shape[0], x.shape[2], x.shape[3], m)
         if key not in self._tiles:
@@ -767,7 +776,9 @@ def prepare_for_inference(model, device='cuda', dtype=torch.float32, channels_la
         model = model.to(dtype)
     elif fuse and channels_last and torch.device(device).type == 'cuda':
         model = swap_depthwise(pair_conv_bn(fuse_bn_act(model)))
-        for m in model.modules():
+        for m in list(model.modules()):
             if hasattr(m, 'hip_ops'):
                 m.hip_ops = True                  # emp_upsample_bilinear + concat buffers written in place
+            if hasattr(m, 'fuse_for_inference'):
+                m.fuse_for_inference()            # RegNet blocks: shortcut + ReLU and the squeeze-excite gate fused
     return model

@@ -334,6 +334,49 @@ def test_model_forward_with_hip_convolutions(force):
         assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (force, k, err, scale)
 
 
+@pytest.mark.parametrize('force', ['hand_written', 'tuned'])
+def test_regnety_forward_with_hip_convolutions(force):
+    """PanopticBiFPN / RegNetY-6.4GF (encoders/regnet.py, blocks.py:35-50): the grouped 3x3 convolutions on
+    emp_gconv3x3_bn_act_nhwc, the 1x1 convolutions with Cin = 144 / 1296 on the 16-wide K-slab variant, the per-pixel
+    squeeze-excite as two fused launches (gate epilogue) and shortcut + ReLU in the last convolution's epilogue --
+    same tolerance against the host module as the MIOpen path.  'tuned': whatever the tuner picks per site."""
+    import copy
+    from empanada_amd.models import PanopticBiFPN, prepare_for_inference, synthesize_weights, tune_fused_convs
+    from empanada_amd.models.panoptic_bifpn import FusedSqueezeExcite, _RegBlock
+    from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
+    torch.manual_seed(0)
+    m = synthesize_weights(PanopticBiFPN(encoder='regnety_6p4gf', num_classes=1)).eval()
+    with torch.no_grad():
+        for head in (m.semantic_head, m.ins_center, m.ins_xy):
+            head.head[1].weight.mul_(1e-3)
+    x = torch.randn(2, 1, 128, 128)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = m(x)
+        g = prepare_for_inference(copy.deepcopy(m), 'cuda')
+        blocks = [mod for mod in g.modules() if isinstance(mod, _RegBlock)]
+        assert len(blocks) == 25 and all(b.fused_tail and isinstance(b.bottleneck.se, FusedSqueezeExcite) for b in blocks)
+        sites = [mod for mod in g.modules() if isinstance(mod, FusedConvBNAct)]
+        if force == 'tuned':
+            rep = tune_fused_convs(g, xd, reps=2)
+            assert len(rep) == len(sites)
+        else:
+            g(xd)                                        # records the call-site shapes
+            n = {'grouped': 0, 'direct': 0}
+            for mod in sites:
+                cand = mod.candidates(mod._seen[1])
+                for impl in ('grouped', 'direct'):
+                    if impl in cand:
+                        mod.impl = impl
+                        n[impl] += 1
+            assert n['grouped'] == 25 and n['direct'] >= 50, n
+        out = g(xd)
+    for k in ref:
+        scale = float(ref[k].abs().max())
+        err = float((out[k].float().cpu() - ref[k]).abs().max())
+        assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (force, k, err, scale)
+
+
 def test_graphed_forward_replays_the_model():
     """models/graphed.py: the batch-1 forward captured as a HIP graph (hand-written kernels + MIOpen in one capture)
     returns what the eager forward returns, for fresh inputs, a second shape, and outputs that stay valid after later

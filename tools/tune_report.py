@@ -1,14 +1,19 @@
 """Print the per-call-site tuning decisions of the PanopticDeepLab forward (batch 32, 512^2) with the
 direct-convolution-equivalent TFLOP/s of every candidate and each site's share of the tuned forward.
-usage: PYTHONPATH=. python tools/tune_report.py"""
+usage: PYTHONPATH=. python tools/tune_report.py [batch size [pdl_r50 | bifpn_r50 | bifpn_regnety]]"""
+import sys
+
 import torch
 
-from empanada_amd.models import PanopticDeepLab, prepare_for_inference, synthesize_weights, tune_fused_convs
+from empanada_amd.models import PanopticBiFPN, PanopticDeepLab, prepare_for_inference, synthesize_weights, tune_fused_convs
 from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
 
 torch.backends.cudnn.benchmark = True
-model = prepare_for_inference(synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)), 'cuda')
-import sys
+which = sys.argv[3] if len(sys.argv) > 3 else 'pdl_r50'
+plain = {'pdl_r50': lambda: PanopticDeepLab(encoder='resnet50', num_classes=1),
+         'bifpn_r50': lambda: PanopticBiFPN(encoder='resnet50', num_classes=1),
+         'bifpn_regnety': lambda: PanopticBiFPN(encoder='regnety_6p4gf', num_classes=1)}[which]()
+model = prepare_for_inference(synthesize_weights(plain), 'cuda')
 B, S = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 512)
 x = torch.rand(B, 1, S, S, device="cuda").contiguous(memory_format=torch.channels_last)
 rep = tune_fused_convs(model, x, reps=10)
