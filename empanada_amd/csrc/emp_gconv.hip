@@ -18,6 +18,9 @@
 #include "emp_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+typedef __attribute__((address_space(3))) const float lds_cf;
 
 #define GC_BM 128
 #define GC_THREADS 256
@@ -147,25 +150,38 @@ __global__ __launch_bounds__(GC_THREADS, (NTL >= 7 ? 2 : 3)) void gconv3x3_f32_k
     store_chunk(0);
     if (S > 1) load_chunk();
     __syncthreads();
+    // Fragment reads are volatile 8-byte loads: the compiler would otherwise pair them into ds_read2_b64, which is
+    // serviced in 16-lane groups on 32 banks (the rows r and r + 8 of a tile collide with this row stride) at half the
+    // rate; a plain ds_read_b64 is serviced in 32-lane groups on 64 banks, for which the layout is conflict-free.
+    // The fragments of slab j + 1 are requested before the MFMAs of slab j.
+    constexpr int NJ = CK / 8;
     for (int s = 0; s < S; ++s) {
         const int buf = s & 1;
         const float *Ab = &As[(buf * GC_BM + wave * 32 + r16) * RS + kq * 2];
         const float *Bb = &Bs[(buf * BN + r16) * RS + kq * 2];
+        f32x2 fa[2][2], fb[2][NTL];
 #pragma unroll
-        for (int j = 0; j < CK / 8; ++j) {
-            float2 fa[2], fb[NTL];
+        for (int i = 0; i < 2; ++i) fa[0][i] = *(const volatile lds_f32x2 *)(lds_cf *)(Ab + i * 16 * RS);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float2 *>(Ab + i * 16 * RS + j * 8);
+        for (int n = 0; n < NTL; ++n) fb[0][n] = *(const volatile lds_f32x2 *)(lds_cf *)(Bb + n * 16 * RS);
 #pragma unroll
-            for (int n = 0; n < NTL; ++n) fb[n] = *reinterpret_cast<const float2 *>(Bb + n * 16 * RS + j * 8);
+        for (int j = 0; j < NJ; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < NJ) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    fa[cur ^ 1][i] = *(const volatile lds_f32x2 *)(lds_cf *)(Ab + i * 16 * RS + (j + 1) * 8);
+#pragma unroll
+                for (int n = 0; n < NTL; ++n)
+                    fb[cur ^ 1][n] = *(const volatile lds_f32x2 *)(lds_cf *)(Bb + n * 16 * RS + (j + 1) * 8);
+            }
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int n = 0; n < NTL; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? fa[i].y : fa[i].x, e ? fb[n].y : fb[n].x,
-                                                                         acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i][e], fb[cur][n][e], acc[i][n], 0, 0, 0);
             if (j == 0) {
                 if (s + 1 < S) store_chunk(buf ^ 1);        // chunk s+1: registers -> the buffer read in iteration s-1
                 if (s + 2 < S) load_chunk();                // chunk s+2: global -> registers
