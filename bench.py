@@ -269,8 +269,9 @@ class Pipeline:
                 torch.sigmoid(logits, out=dst)
             else:
                 torch.softmax(logits, dim=1, out=dst)
-            chk += out['ctr_hmp'].float().sum(dtype=torch.float64) + out['offsets'].float().sum(dtype=torch.float64)
-        return prob, chk + prob.sum(dtype=torch.float64)
+            chk += (out['ctr_hmp'].float().sum(dtype=torch.float64) + out['offsets'].float().sum(dtype=torch.float64)
+                    + dst.sum(dtype=torch.float64))          # per call: the fp64 temporary stays one batch large
+        return prob, chk
 
     def postprocess(self, heads, out_host):
         """stack mode: probabilities -> labelled slab in pinned host memory.  Same code path for 1 and N ranks

@@ -561,7 +561,6 @@ def merge_objects_from_tiles(tiles, overlap_rle=None):
     """consensus.py:526-625 -- objects of overlapping tiles that intersect are joined; with `overlap_rle`, an object
     seen in a single tile that lies by more than 10 % inside the overlap region is dropped.  Pair intersections and
     all joins run on the GPU in one launch each."""
-    from .array_utils import rle_ioa
     tile_indices, object_labels, object_boxes, object_starts, object_runs = [], [], [], [], []
     for tile_idx, tile_instances in enumerate(tiles):
         for instance_id, attr in tile_instances.items():
@@ -588,17 +587,28 @@ def merge_objects_from_tiles(tiles, overlap_rle=None):
         groups.append(lst)
     joined = vote_groups(groups, 1)
 
+    # rle_ioa(overlap, object) of every object seen in one tile only (consensus.py:606-613), all in ONE launch
+    dropped = set()
+    if overlap_rle is not None:
+        single = [ci for ci, (cluster, vr) in enumerate(zip(clusters, joined)) if len(cluster) < 2 and np.any(vr)]
+        if single:
+            from .array_utils import rle_pair_intersections
+            inter = rle_pair_intersections([np.asarray(overlap_starts)] + [joined[ci][:, 0] for ci in single],
+                                           [np.asarray(overlap_runs)] + [joined[ci][:, 1] - joined[ci][:, 0] for ci in single],
+                                           [[0, k + 1] for k in range(len(single))])
+            for ci, it in zip(single, inter):
+                area = int(np.sum(joined[ci][:, 1] - joined[ci][:, 0]))
+                if np.float64(int(it)) / np.float64(area) > 0.1:
+                    dropped.add(ci)
+
     instance_id = int(np.min(object_labels))
     instances = {}
-    for cluster, voted_ranges in zip(clusters, joined):
+    for ci, (cluster, voted_ranges) in enumerate(zip(clusters, joined)):
         merged_box = graph.nodes[cluster[0]]['box']
         for node_id in cluster[1:]:
             merged_box = merge_boxes(merged_box, graph.nodes[node_id]['box'])
-        if overlap_rle is not None and len(cluster) < 2 and np.any(voted_ranges):
-            ov_ioa = rle_ioa(np.asarray(overlap_starts), np.asarray(overlap_runs), voted_ranges[:, 0],
-                             voted_ranges[:, 1] - voted_ranges[:, 0])
-            if ov_ioa > 0.1:
-                voted_ranges = np.zeros((0, 2), dtype=np.int64)
+        if ci in dropped:
+            voted_ranges = np.zeros((0, 2), dtype=np.int64)
         if np.any(voted_ranges):
             instances[instance_id] = {'box': tuple(int(x) for x in merged_box), 'starts': voted_ranges[:, 0],
                                       'runs': voted_ranges[:, 1] - voted_ranges[:, 0]}

@@ -545,7 +545,13 @@ static CgPlan cg_plan(int64_t M, int Cout, int batch, bool has_res, bool res_vec
     p.narrow = Cout <= 64 || (Cout % 128 != 0 && Cout % 128 <= 64 && Cout < 512) || (may_split_n && wide_blocks < 256);
     p.tiles_m = (int)emp_cdiv(M, CG_BM);
     p.tiles_n = (int)emp_cdiv(Cout, p.narrow ? 64 : 128);
-    p.respf = has_res && res_vec_ok && Cout % (p.narrow ? 64 : 128) == 0;
+    static const char *fnarrow = getenv("EMP_CONV_NARROW");    // experiments only: "1" forces 64-wide cout tiles
+    static const char *norespf = getenv("EMP_CONV_NO_RESPF");  // experiments only
+    if (fnarrow && fnarrow[0] == '1') {
+        p.narrow = true;
+        p.tiles_n = (int)emp_cdiv(Cout, 64);
+    }
+    p.respf = has_res && res_vec_ok && Cout % (p.narrow ? 64 : 128) == 0 && !norespf;
     static const char *force = getenv("EMP_CONV_BK");          // experiments only: "16" / "32"
     const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n * batch;
     p.slab = blocks > 512 ? 16 : 32;

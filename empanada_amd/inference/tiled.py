@@ -23,6 +23,8 @@ from .rle import stack_to_rle_segs
 
 __all__ = ['stitch_slice', 'tiled_panoptic_stack']
 
+TIMERS = {}           # host seconds spent per stage of tiled_panoptic_stack (accumulated; tools/bench_tiled.py)
+
 
 def stitch_slice(tile_rle_segs, tiler, labels, thing_list, use_overlap=True):
     """rle_segs of one slice's tiles (tile frame) -> rle_seg of the plane (plane frame): translate, then per class
@@ -66,9 +68,11 @@ def tiled_panoptic_stack(tile_heads, n_slices, tiler, labels, *, thing_list, lab
     median_kernel_size, coarse_boundaries).
     Returns pan (D, H, W) uint32 on the device (and the per-slice stitched rle_segs if return_rle)."""
     _hip.require_gpu()
+    import time
     H, W = tiler.image_shape
     labels, thing_list = list(labels), list(thing_list)
     per_tile = []
+    t_start = time.perf_counter()
     for i in range(len(tiler)):
         h = tile_heads(i)
         pan, emitted = panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], thing_list=thing_list,
@@ -80,9 +84,17 @@ def tiled_panoptic_stack(tile_heads, n_slices, tiler, labels, *, thing_list, lab
         per_tile.append(segs)
     out = torch.zeros((n_slices, H, W), dtype=torch.int32, device='cuda').view(torch.uint32)
     stitched = []
+    t_tiles = time.perf_counter()
+    t_paint = 0.0
     for z in range(n_slices):
         rs = stitch_slice([per_tile[i][z] for i in range(len(tiler))], tiler, labels, thing_list, use_overlap)
+        tp = time.perf_counter()
         _paint(rs, (H, W), out[z])
+        t_paint += time.perf_counter() - tp
         if return_rle:
             stitched.append(rs)
+    t_end = time.perf_counter()
+    TIMERS['tiles_pixels_and_runs'] = TIMERS.get('tiles_pixels_and_runs', 0.0) + t_tiles - t_start
+    TIMERS['stitch'] = TIMERS.get('stitch', 0.0) + t_end - t_tiles - t_paint
+    TIMERS['paint'] = TIMERS.get('paint', 0.0) + t_paint
     return (out, stitched) if return_rle else out
