@@ -34,7 +34,7 @@ struct GConvGeom {
 };
 
 template <int CK, int NTL>
-__global__ __launch_bounds__(GC_THREADS, (NTL >= 7 ? 2 : 3)) void gconv3x3_f32_kernel(GConvGeom g)
+__global__ __launch_bounds__(GC_THREADS, (NTL >= 6 ? 2 : 3)) void gconv3x3_f32_kernel(GConvGeom g)
 {
     constexpr int RS = CK + 4;                          // LDS row (floats)
     constexpr int F4R = CK / 4;                         // float4 per staged row
