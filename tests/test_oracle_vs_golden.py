@@ -217,6 +217,26 @@ def test_get_panoptic_segmentation_golden():
             assert len(np.unique(pan)) > 2
 
 
+def test_data_post_fixture_of_the_reference():
+    """The reference's own post-processing test (tests/test_data_post.py:13-43): its panoptic ground-truth mask ->
+    training targets -> get_panoptic_segmentation.  Fixture = mask, targets and the REFERENCE's output
+    (oracle/gen_golden_r3.py).  The oracle must return the same labels and centres, and -- the reference test's own
+    assertion -- PQ per class against the mask is 1 to three decimals."""
+    from empanada_amd.evaluation import volume_pq
+    g = load_golden('data_post')
+    sem = g['sem'].astype(np.int64)[None, None]
+    pan, ctr = OP.get_panoptic_segmentation(sem, g['ctr_hmp'][None], g['offsets'][None], [2], 1000, 0, 0, 0.1, 7)
+    np.testing.assert_array_equal(pan, g['pan'])
+    np.testing.assert_array_equal(ctr, g['ctr'])
+    assert ctr.shape == (1, 7, 2)
+    for c in (1, 2, 3):
+        gt = np.where(g['mask'] // 1000 == c, g['mask'], 0)
+        pr = np.where(g['pan'][0, 0] // 1000 == c, g['pan'][0, 0], 0)
+        pq, n_gt, n_pr, n_m = volume_pq(gt, pr)
+        assert n_gt == n_pr == n_m == (7 if c == 2 else 1)
+        np.testing.assert_almost_equal(pq, 1.0, decimal=3)
+
+
 def test_forward_multigpu_golden():
     """forward_multigpu (patterns.py:279-350): the oracle's restatement against the rle_stack the reference sent"""
     g = load_golden('forward_multigpu')

@@ -588,6 +588,18 @@ def test_evaluator_on_tracker_jsons(tmp_path):
     assert ev(paths[0], paths[0])['pq'] == pytest.approx(1.0, abs=1e-4)
 
 
+def test_data_post_fixture_of_the_reference_gpu():
+    """The mask of the reference's tests/test_data_post.py (real organelle shapes, two stuff classes around seven
+    things) through the HIP get_panoptic_segmentation: labels and centres identical to the reference's output."""
+    from empanada_amd.inference.postprocess import get_panoptic_segmentation
+    g = load_golden('data_post')
+    sem = torch.from_numpy(g['sem'].astype(np.int64))[None, None].cuda()
+    pan, ctr = get_panoptic_segmentation(sem, torch.from_numpy(g['ctr_hmp'])[None].cuda(),
+                                         torch.from_numpy(g['offsets'])[None].cuda(), [2], 1000, 0, 0, 0.1, 7)
+    np.testing.assert_array_equal(pan.cpu().numpy(), g['pan'])
+    np.testing.assert_array_equal(ctr.cpu().numpy(), g['ctr'])
+
+
 def test_get_panoptic_segmentation_golden():
     """P6 (postprocess.py:298-356): shape checks + centres + grouping + fusion in one call, against the reference"""
     from empanada_amd.inference.postprocess import get_panoptic_segmentation
