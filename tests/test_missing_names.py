@@ -62,3 +62,21 @@ def test_detection_metric_kats():
     assert EV.f1_50(**empty) == 1 and EV.ap(**empty) == 1 and EV.precision_50(**empty) == 1
     assert EV.recall_50(**empty) == 1 and EV.panoptic_quality(**empty) == 1
     assert EV.iou(np.zeros((0, 2)), np.zeros((0, 2))) == 1 and EV.iou(np.zeros((0, 2)), np.array([[1, 2]])) == 0
+
+
+def test_reference_metric_kat_panoptic_squares():
+    """The panoptic known-answer case of the reference's tests/test_metrics.py:73-119 (three squares, one prediction just
+    under IoU 0.5), evaluated with this package's volume_pq: PQ per class [1, 0.5]; at IoU threshold 0.4 every
+    instance of class 2 is matched (F1 = 1)."""
+    import numpy as np
+    from empanada_amd.evaluation import volume_pq
+    gt = np.zeros((128, 128), dtype=np.int64)
+    gt[:32, :32], gt[:32, -32:], gt[-32:, -32:] = 1001, 2001, 2002
+    pred = np.zeros((128, 128), dtype=np.int64)
+    pred[:32, :32], pred[:15, -32:], pred[-32:, -32:] = 1001, 2002, 2001
+    expected = {1: 1.0, 2: 0.5}
+    for c in (1, 2):
+        pq, n_gt, n_pr, n_m = volume_pq(np.where(gt // 1000 == c, gt, 0), np.where(pred // 1000 == c, pred, 0))
+        np.testing.assert_almost_equal(pq, expected[c], decimal=3)
+    _, n_gt, n_pr, n_m = volume_pq(np.where(gt // 1000 == 2, gt, 0), np.where(pred // 1000 == 2, pred, 0), iou_thr=0.4)
+    assert n_gt == n_pr == n_m == 2                      # tp 2, fp 0, fn 0 -> F1 = 1
