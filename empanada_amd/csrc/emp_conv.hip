@@ -75,6 +75,8 @@ __device__ __forceinline__ void cg_wait_vm()
 //        over the row's BN/4 lanes in ascending order, one atomicAdd per (row, q, cout tile) into a zeroed planar
 //        accumulator.  With at most two cout tiles the result does not depend on the order of the atomics
 //        (0 + a + b == 0 + b + a).  The activation itself need not be written (out == NULL).
+// GATE:  epilogue out = residual * sigmoid(acc * scale + shift) (the per-pixel squeeze-excite of the RegNet blocks; a
+//        template flag, not a run-time branch: a branch in the shared epilogue cost the residual-prefetch variant 3-5 %)
 // GLDS:  the K-slabs go from global memory straight into LDS (no staging registers, no ds_write, no masking: invalid
 //        rows read a zero page).  The LDS image of a slab is lane-linear, i.e. unpadded rows; bank conflicts of the
 //        16-byte fragment reads are avoided by XOR-swizzling the 16-byte chunk index with the row ON THE SOURCE SIDE
@@ -82,7 +84,7 @@ __device__ __forceinline__ void cg_wait_vm()
 //        Ring of 3 slabs for BK = 16 (loads run two slabs ahead, `s_waitcnt vmcnt(loads of one slab)` before the
 //        barrier), 2 for BK = 32.  Measured motivation: without the register -> LDS stage the same loop runs at 96 %
 //        of the matrix peak instead of 83 %.
-template <int NT, int MODE, bool RESPF = false, int BK = 32, bool PROJ = false, bool GLDS = false>
+template <int NT, int MODE, bool RESPF = false, int BK = 32, bool PROJ = false, bool GLDS = false, bool GATE = false>
 __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32_kernel(ConvGeom g)
 {
     constexpr int BN = 64 * NT;
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
                 for (int e = 0; e < 4; ++e) {
                     if (g.scale) v[e] = __fmul_rn(v[e], sc[e]);
                     if (g.shift) v[e] = __fadd_rn(v[e], sh[e]);
-                    if (g.relu == 2) {                      // squeeze-excite gate: res * sigmoid(v)
+                    if constexpr (GATE) {                   // squeeze-excite gate: res * sigmoid(v)
                         v[e] = __fmul_rn(rr[e], __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v[e]))));
                     } else {
                         if (g.res) v[e] = __fadd_rn(v[e], rr[e]);
@@ -604,7 +606,7 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     g.M = (int64_t)N * OH * OW; g.out_ps = out_pixel_stride; g.res_ps = res_pixel_stride;
     g.x_bs = g.w_bs = g.out_bs = 0; g.tiles = nullptr; g.proj_w = nullptr; g.proj_out = nullptr; g.proj_n = 0; g.hw = 1;
     const bool res_vec_ok = (res_pixel_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
-    const CgPlan pl = cg_plan(g.M, Cout, 1, residual != nullptr, res_vec_ok, true, Cin);
+    const CgPlan pl = cg_plan(g.M, Cout, 1, residual != nullptr && relu != 2, res_vec_ok, true, Cin);
     const bool narrow = pl.narrow, respf = pl.respf, bk16 = pl.slab == 16;
     EMP_REQUIRE((int64_t)pl.tiles_m * pl.tiles_n < (1LL << 28), "conv: too many tiles");
     g.tiles_m = pl.tiles_m;
@@ -612,7 +614,11 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     const int T = g.tiles_m * g.tiles_n;
     const int grid = 8 * ((T + 7) / 8);
 #define CG_GO(NT_, RES_, BK_, GL_) hipLaunchKernelGGL((conv_igemm_f32_kernel<NT_, 0, RES_, BK_, false, GL_>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g)
-    if (narrow) {
+#define CG_GATE(NT_, BK_) hipLaunchKernelGGL((conv_igemm_f32_kernel<NT_, 0, false, BK_, false, true, true>), dim3(grid), dim3(CG_THREADS), 0, emp_stream(stream), g)
+    if (relu == 2) {                         // gate epilogue: LDS-direct staging, residual read in the epilogue
+        if (narrow) { if (bk16) CG_GATE(1, 16); else CG_GATE(1, 32); }
+        else { if (bk16) CG_GATE(2, 16); else CG_GATE(2, 32); }
+    } else if (narrow) {
         if (respf) { if (pl.glds) CG_GO(1, true, 32, true); else CG_GO(1, true, 32, false); }
         else if (pl.glds) { if (bk16) CG_GO(1, false, 16, true); else CG_GO(1, false, 32, true); }
         else { if (bk16) CG_GO(1, false, 16, false); else CG_GO(1, false, 32, false); }
@@ -622,6 +628,7 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
         else { if (bk16) CG_GO(2, false, 16, false); else CG_GO(2, false, 32, false); }
     }
 #undef CG_GO
+#undef CG_GATE
     EMP_CHECK_LAUNCH("emp_conv_bn_act_nhwc");
     return EMP_OK;
 }

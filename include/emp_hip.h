@@ -110,7 +110,8 @@ int emp_conv_k_slab(int64_t M, int Cout, int batch, int has_residual);
 int emp_conv_k_slab_cin(int64_t M, int Cout, int batch, int has_residual, int Cin);
 /* relu == 2 selects the squeeze-excite gate epilogue (SqueezeExcite.forward, empanada/models/blocks.py:35-50:
  * x * sigmoid(conv(s) + bias)): out = residual * (1 / (1 + expf(-(acc * scale + shift)))), residual = the gated
- * tensor x (required); the division and the product are separate fp32 roundings, expf is the device library's.
+ * tensor x (required); the division and the product are separate fp32 roundings, expf is the device library's;
+ * its K-slab is emp_conv_k_slab_cin(M, Cout, 1, 0, Cin) (the residual-prefetch variant is never used for it).
  * Cin % 16 == 0 (round 2; was 32).                                                                            */
 int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
                          const float *residual, int64_t res_pixel_stride, int relu, int N, int H, int W,

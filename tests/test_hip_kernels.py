@@ -611,7 +611,8 @@ def test_conv_cin_multiple_of_16(hip, cfg):
     np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
 
 
-@pytest.mark.parametrize('cfg', [(2, 16, 16, 48, 144), (1, 8, 8, 80, 288), (8, 64, 64, 144, 576), (1, 4, 4, 336, 1296)])
+@pytest.mark.parametrize('cfg', [(2, 16, 16, 48, 144), (1, 8, 8, 80, 288), (8, 64, 64, 144, 576), (1, 4, 4, 336, 1296),
+                                 (2, 16, 16, 64, 256), (8, 64, 64, 96, 128)])
 def test_conv_gate_epilogue(hip, cfg):
     """relu == 2 (squeeze-excite gate, blocks.py:35-50): out = x * sigmoid(conv(s) + b).  The accumulator is
     bit-exact (same kernel); expf is the device library's, so the gate is compared with the oracle (glibc expf) and
@@ -627,7 +628,7 @@ def test_conv_gate_epilogue(hip, cfg):
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     got = hip.conv_bn_act_nhwc(s_in.cuda().contiguous(memory_format=torch.channels_last), w_okkc.cuda(), None, b.cuda(),
                                xd, 'gate').cpu()
-    slab = hip.conv_k_slab(N * H * W, Cout, 1, True, Cin)
+    slab = hip.conv_k_slab(N * H * W, Cout, 1, False, Cin)      # the gate variant never takes the residual-prefetch plan
     exp = torch.from_numpy(OD.conv_bn_act_nhwc(s_in.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), None, b.numpy(),
                                                x.permute(0, 2, 3, 1).numpy(), 'gate', slab=slab)).permute(0, 3, 1, 2)
     assert torch.all((got - exp).abs() <= 5e-7 * x.abs())
