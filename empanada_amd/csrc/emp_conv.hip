@@ -474,6 +474,21 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
                             if (co + e < g.Cout) rr[e] = g.res[p * g.res_ps + co + e];
                     }
                 }
+                if (RESPF && g.scale && g.shift) {          // the common case of the prefetch variant, straight-line
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]), rr[e]);
+                    if (g.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                } else if (!RESPF && !GATE && !g.res && g.scale && g.shift) {   // BN (+ ReLU) only
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);
+                    if (g.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                } else
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (g.scale) v[e] = __fmul_rn(v[e], sc[e]);
