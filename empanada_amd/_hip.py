@@ -55,6 +55,7 @@ SIGNATURES = {
     'emp_slices_to_input': (_I, [_P, _L, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     'emp_pointwise_out_nhwc': (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),
     'emp_bn_relu_maxpool_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    'emp_stem_conv7_bn_relu_maxpool': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
@@ -563,6 +564,8 @@ def gconv3x3_bn_act_nhwc(x, w_okkc, groups, scale=None, shift=None, relu=False, 
     if out is None:
         out = torch.empty((N, C, OH, OW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     assert out.shape == (N, C, OH, OW) and out.stride(1) == 1
+    if N == 0:
+        return out
     ops = out.stride(3)
     assert out.stride(2) == OW * ops and out.stride(0) == OH * OW * ops, "NHWC channel slice required"
     call('emp_gconv3x3_bn_act_nhwc', x.data_ptr(), C, _ptr(w_okkc), _ptr(scale), _ptr(shift), int(bool(relu)),
@@ -664,6 +667,21 @@ def bn_relu_maxpool_nhwc(x, scale, shift):
                     memory_format=torch.channels_last)
     call('emp_bn_relu_maxpool_nhwc', x.data_ptr(), _ptr(scale), _ptr(shift), N, H, W, C, y.data_ptr(), stream(),
          alg_bytes=4 * (x.numel() + y.numel()))
+    return y
+
+
+def stem_conv7_bn_relu_maxpool(x, w_tc, scale, shift):
+    """max_pool2d(relu(bn(conv2d(x, w, stride 2, padding 3))), 3, 2, 1) of the ResNet stem in one kernel
+    (emp_stem_conv7_bn_relu_maxpool).  x: (N,1,H,W) fp32 contiguous; w_tc: (49, 64); returns (N,64,PH,PW) channels_last."""
+    require_gpu()
+    N, C, H, W = x.shape
+    assert C == 1 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    assert tuple(w_tc.shape) == (49, 64) and w_tc.is_contiguous()
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    y = torch.empty((N, 64, PH, PW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    call('emp_stem_conv7_bn_relu_maxpool', x.data_ptr(), _ptr(w_tc), _ptr(scale), _ptr(shift), N, H, W, y.data_ptr(),
+         stream(), alg_bytes=4 * (x.numel() + y.numel()), alg_flops=2 * N * OH * OW * 64 * 49)
     return y
 
 

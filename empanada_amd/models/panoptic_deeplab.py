@@ -359,15 +359,26 @@ class ResNetEncoder(nn.Module):
         return nn.Sequential(*mods)
 
     hip_ops = False
+    _stem_w = None                    # (49, 64) filter table of the fused stem, built at the first call
 
     def forward(self, x):
         if (self.hip_ops and isinstance(self.bn1, FusedBNAct) and x.is_cuda and x.dtype == torch.float32
                 and self.maxpool.kernel_size == 3 and self.maxpool.stride == 2 and self.maxpool.padding == 1):
             from .. import _hip
-            y = self.conv1(x)
-            if not y.is_contiguous(memory_format=torch.channels_last):
-                y = y.contiguous(memory_format=torch.channels_last)
-            p1 = _hip.bn_relu_maxpool_nhwc(y, self.bn1.scale, self.bn1.shift)       # stem epilogue in one pass
+            c1 = self.conv1
+            if (c1.in_channels == 1 and c1.out_channels == 64 and c1.kernel_size == (7, 7) and c1.stride == (2, 2)
+                    and c1.padding == (3, 3) and c1.bias is None and c1.weight.dtype == torch.float32):
+                # the whole stem in one kernel (emp_stem_conv7_bn_relu_maxpool): the 1/2-resolution activation never
+                # leaves the CU.  (N,1,H,W) is the same memory in NCHW and NHWC.
+                if self._stem_w is None:
+                    self._stem_w = c1.weight.detach()[:, 0].reshape(64, 49).t().contiguous()
+                xs = x if x.is_contiguous() else x.contiguous()
+                p1 = _hip.stem_conv7_bn_relu_maxpool(xs, self._stem_w, self.bn1.scale, self.bn1.shift)
+            else:
+                y = self.conv1(x)
+                if not y.is_contiguous(memory_format=torch.channels_last):
+                    y = y.contiguous(memory_format=torch.channels_last)
+                p1 = _hip.bn_relu_maxpool_nhwc(y, self.bn1.scale, self.bn1.shift)   # stem epilogue in one pass
         elif isinstance(self.bn1, FusedBNAct):
             p1 = self.maxpool(self.bn1(self.conv1(x)))
         else:

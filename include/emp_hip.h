@@ -223,6 +223,17 @@ int emp_pointwise_out_nhwc(const float *x, const float *w, const float *bias, in
 int emp_bn_relu_maxpool_nhwc(const float *x, const float *scale, const float *shift, int N, int H, int W,
                              int C, float *y, void *stream);
 
+/* ---- D9: the whole ResNet stem on a one-channel image: conv 7x7 / 2 + BatchNorm(eval) + ReLU + MaxPool 3x3 / 2 ----
+ * replaces conv1 -> bn1 -> relu -> maxpool of ResNet.forward     empanada/models/encoders/resnet.py:186-188,217-222
+ * conv[n, oy, ox, co] = ONE fp32 fma chain from +0 over the 49 taps in raster order of x[n, 2oy-3+ky, 2ox-3+kx] *
+ * w_tc[7ky+kx, co] (taps outside the image enter as 0; evaluated on the vector ALUs, two channels per v_pk_fma_f32);
+ * y = D7 of conv: max over the 3x3 window (outside the image: skipped) of max(conv*scale[co] + shift[co], 0).
+ * x (N, H, W) fp32, w_tc (49, 64) = the Conv2d(1, 64, 7) weight as [tap][cout], 16-byte aligned,
+ * y (N, PH, PW, 64) NHWC with OH = (H-1)/2+1, PH = (OH-1)/2+1 (likewise W).  The half-resolution activation is never
+ * written.                                                                                                        */
+int emp_stem_conv7_bn_relu_maxpool(const float *x, const float *w_tc, const float *scale, const float *shift,
+                                   int N, int H, int W, float *y, void *stream);
+
 /* ---- P1 + P2: recursive median over a resident stack, fused with hardening ----------------
  * replaces _MedianQueue.get_next/get_median/end   empanada/inference/engines.py:47-90
  *          _harden_seg / harden_seg               engines.py:114-121, inference/patterns.py:242-251

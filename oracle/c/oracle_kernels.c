@@ -297,3 +297,24 @@ void emp_oracle_gconv3x3_bn_act_nhwc(const float *x, const float *w, const float
                 }
             }
 }
+
+/* D9 (emp_stem_conv7_bn_relu_maxpool), convolution part: Conv2d(1, Cout, 7, stride 2, padding 3) of the ResNet stem
+ * (empanada/models/encoders/resnet.py:186-188,217-222) on a one-channel image: one fmaf chain from +0 per output over
+ * the 49 taps in raster order, taps outside the image enter as x = 0.  w_tc: (49, Cout).  out: (N, OH, OW, Cout). */
+void emp_oracle_conv7s2_c1(const float *x, const float *w_tc, int N, int H, int W, int Cout, float *out)
+{
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox)
+                for (int co = 0; co < Cout; ++co) {
+                    float acc = 0.0f;
+                    for (int ky = 0; ky < 7; ++ky)
+                        for (int kx = 0; kx < 7; ++kx) {
+                            const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
+                            const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((int64_t)n * H + iy) * W + ix] : 0.0f;
+                            acc = fmaf(xv, w_tc[(ky * 7 + kx) * Cout + co], acc);
+                        }
+                    out[(((int64_t)n * OH + oy) * OW + ox) * Cout + co] = acc;
+                }
+}

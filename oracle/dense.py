@@ -219,6 +219,22 @@ def bn_relu_maxpool_nhwc(x_nhwc, scale, shift):
     return out
 
 
+def stem_conv7_bn_relu_maxpool(x_nhw, w_tc, scale, shift):
+    """The ResNet stem (encoders/resnet.py:186-188,217-222: conv1 7x7 / 2 -> bn1 -> relu -> maxpool 3x3 / 2) on a
+    one-channel image x (N,H,W): convolution as one fmaf chain per output over the 49 taps in raster order (plain C),
+    then the D7 epilogue above.  w_tc: (49, Cout) = conv1.weight[:, 0].reshape(Cout, 49).T.  Order of include/emp_hip.h
+    (D9); pinned against torch's conv2d + max_pool2d within fp32 rounding in tests/test_oracle_dense.py."""
+    x = np.ascontiguousarray(x_nhw, dtype=np.float32)
+    w = np.ascontiguousarray(w_tc, dtype=np.float32)
+    N, H, W = x.shape
+    Cout = w.shape[1]
+    assert w.shape[0] == 49
+    conv = np.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), dtype=np.float32)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    lib().emp_oracle_conv7s2_c1(x.ctypes.data_as(f32p), w.ctypes.data_as(f32p), N, H, W, Cout, conv.ctypes.data_as(f32p))
+    return bn_relu_maxpool_nhwc(conv, scale, shift)
+
+
 def wino4_filter_transform(w_oihw):
     """fp32(G g G^T) for F(4x4,3x3) in the elementwise fp64 order of empanada_amd._hip.wino4_filter_transform"""
     g = np.asarray(w_oihw, dtype=np.float64)

@@ -585,6 +585,53 @@ def test_gconv3x3_bn_act_nhwc(hip, cfg):
     np.testing.assert_array_equal(got0.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp0.view(np.uint32))
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 64), (1, 37, 45), (3, 130, 70), (1, 7, 9), (2, 256, 320), (1, 1, 1)])
+def test_stem_conv7_bn_relu_maxpool(hip, shape):
+    """emp_stem_conv7_bn_relu_maxpool (D9): bit-exact against the oracle (fma chain over the 49 taps in raster order,
+    then the D7 epilogue); within fp32 rounding of torch's conv2d -> affine -> relu -> max_pool2d:
+    |err| <= 2e-6 * sum|x||w| * |scale| + 1e-6.  Odd sizes: partial tiles, windows cut by every border."""
+    from oracle import dense as OD
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(N, 1, H, W, generator=g)
+    w = torch.randn(64, 1, 7, 7, generator=g) * (1.0 / 7)
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.5
+    w_tc = w[:, 0].reshape(64, 49).t().contiguous()
+    got = hip.stem_conv7_bn_relu_maxpool(x.cuda(), w_tc.cuda(), sc.cuda(), sh.cuda())
+    exp = OD.stem_conv7_bn_relu_maxpool(x[:, 0].numpy(), w_tc.numpy(), sc.numpy(), sh.numpy())
+    np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    conv = torch.nn.functional.conv2d(x, w, stride=2, padding=3)
+    ref = torch.nn.functional.max_pool2d(torch.relu(conv * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 3, 2, 1)
+    bound = torch.nn.functional.max_pool2d(torch.nn.functional.conv2d(x.abs(), w.abs(), stride=2, padding=3)
+                                           * sc.view(1, -1, 1, 1), 3, 2, 1)
+    assert got.shape == ref.shape and torch.all((got.cpu() - ref).abs() <= 2e-6 * bound + 1e-6)
+    # the two-kernel path it replaces (MIOpen convolution + emp_bn_relu_maxpool_nhwc) agrees to the same bound
+    y = conv.cuda().contiguous(memory_format=torch.channels_last)
+    two = hip.bn_relu_maxpool_nhwc(y, sc.cuda(), sh.cuda())
+    assert torch.all((got - two).abs().cpu() <= 2e-6 * bound + 1e-6)
+
+
+def test_gconv_and_gate_argument_errors(hip):
+    """emp_gconv3x3_bn_act_nhwc / the gate epilogue refuse what they cannot compute (EMP_EINVAL -> HipError, nothing
+    launched); an empty batch is a no-op."""
+    x = torch.zeros(1, 36, 8, 8, device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(36, 3, 3, 12, device='cuda')
+    with pytest.raises(hip.HipError):
+        hip.gconv3x3_bn_act_nhwc(x, w, 3)                                    # group width 12 is not a multiple of 8
+    x = torch.zeros(1, 32, 8, 8, device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(32, 3, 3, 16, device='cuda')
+    with pytest.raises(hip.HipError):
+        hip.gconv3x3_bn_act_nhwc(x, w, 2, stride=3)                          # stride 1 or 2 only
+    x0 = torch.zeros(0, 32, 8, 8, device='cuda').contiguous(memory_format=torch.channels_last)
+    assert hip.gconv3x3_bn_act_nhwc(x0, w, 2).shape == (0, 32, 8, 8)
+    w1 = torch.zeros(16, 1, 1, 32, device='cuda')
+    with pytest.raises(hip.HipError):
+        hip.conv_bn_act_nhwc(x, w1, None, None, None, 'gate')                # the gate needs the gated tensor
+    x24 = torch.zeros(1, 24, 8, 8, device='cuda').contiguous(memory_format=torch.channels_last)
+    with pytest.raises(hip.HipError):
+        hip.conv_bn_act_nhwc(x24, torch.zeros(16, 1, 1, 24, device='cuda'))   # Cin % 16 != 0
+
+
 @pytest.mark.parametrize('cfg', [
     (2, 16, 16, 144, 144, False, True),      # RegNetY widths: Cin a multiple of 16 only -> 16-wide K-slabs
     (2, 16, 16, 144, 144, True, True),       # with the shortcut (no residual prefetch on this path)

@@ -109,3 +109,20 @@ def test_gate_oracle_vs_torch():
                                                None, b.numpy(), _nhwc(x), 'gate', slab=16)).permute(0, 3, 1, 2)
     ref = x.double() * torch.sigmoid(F.conv2d(s_in.double(), w.double(), b.double()))
     assert torch.all((got.double() - ref).abs() <= 2e-6 * x.abs() + 1e-7)
+
+
+@pytest.mark.parametrize('shape', [(2, 37, 45), (1, 64, 64), (1, 9, 7)])
+def test_stem_oracle_vs_torch(shape):
+    """oracle.dense.stem_conv7_bn_relu_maxpool against conv1 -> bn1 -> relu -> maxpool of the reference's ResNet
+    (encoders/resnet.py:186-188,217-222) evaluated by torch in float64: |err| <= 2e-6 * sum|x||w| * |scale| + 1e-6."""
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(N, 1, H, W, generator=g)
+    w = torch.randn(64, 1, 7, 7, generator=g) * (1.0 / 7)
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.5
+    got = torch.from_numpy(OD.stem_conv7_bn_relu_maxpool(x[:, 0].numpy(), w[:, 0].reshape(64, 49).t().contiguous().numpy(),
+                                                         sc.numpy(), sh.numpy())).permute(0, 3, 1, 2)
+    conv = F.conv2d(x.double(), w.double(), stride=2, padding=3)
+    ref = F.max_pool2d(torch.relu(conv * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)), 3, 2, 1)
+    bound = F.max_pool2d(F.conv2d(x.abs(), w.abs(), stride=2, padding=3) * sc.view(1, -1, 1, 1), 3, 2, 1)
+    assert got.shape == ref.shape and torch.all((got.double() - ref).abs() <= 2e-6 * bound + 1e-6)
