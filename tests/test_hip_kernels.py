@@ -611,6 +611,24 @@ def test_stem_conv7_bn_relu_maxpool(hip, shape):
     assert torch.all((got - two).abs().cpu() <= 2e-6 * bound + 1e-6)
 
 
+@pytest.mark.parametrize('gw', list(range(8, 129, 8)))
+def test_gconv_every_group_width(hip, gw):
+    """every (chunk, cout-tile) instantiation of gconv3x3_f32_kernel that ships -- group widths 8, 16, .., 128 -- bit-exact
+    against the oracle, stride 1 and 2, on a shape with partial pixel tiles"""
+    from oracle import dense as OD
+    G, N, H, W = 2, 1, 11, 13
+    C = G * gw
+    g = torch.Generator().manual_seed(gw)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = (torch.randn(C, gw, 3, 3, generator=g) * (1.0 / (gw * 9) ** 0.5)).permute(0, 2, 3, 1).contiguous()
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    for stride in (1, 2):
+        got = hip.gconv3x3_bn_act_nhwc(xd, w.cuda(), G, sc.cuda(), sh.cuda(), True, stride)
+        exp = OD.gconv3x3_bn_act_nhwc(x.permute(0, 2, 3, 1).numpy(), w.numpy(), G, sc.numpy(), sh.numpy(), True, stride)
+        np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
+
+
 def test_gconv_and_gate_argument_errors(hip):
     """emp_gconv3x3_bn_act_nhwc / the gate epilogue refuse what they cannot compute (EMP_EINVAL -> HipError, nothing
     launched); an empty batch is a no-op."""
