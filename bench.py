@@ -73,7 +73,7 @@ DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 
                  'emp_wino_output_transform', 'emp_wino4_input_transform', 'emp_wino4_output_transform',
                  'emp_wino3_input_transform', 'emp_wino3_output_transform',
                  'emp_pointwise_out_nhwc', 'emp_bn_relu_maxpool_nhwc', 'emp_slices_to_input', 'emp_gconv3x3_bn_act_nhwc',
-                 'emp_stem_conv7_bn_relu_maxpool')
+                 'emp_stem_conv7_bn_relu_maxpool', 'emp_logits_to_prob')
 MFMA_KERNELS = ('emp_conv_bn_act_nhwc', 'emp_conv_bn_act_proj_nhwc', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
                 'emp_gconv3x3_bn_act_nhwc')
 MFMA_F32_PEAK_TFLOPS = 157.3                   # dense fp32 matrix peak (MI355X_MICROARCH.md)
@@ -266,7 +266,9 @@ class Pipeline:
             out = model(x.contiguous(memory_format=torch.channels_last))
             logits = out['sem_logits'][..., :h, :w].float()          # logits_to_prob, engines.py:22-30
             dst = prob[s - lo:s - lo + x.shape[0]]                   # written in place: no temporary + device copy
-            if nc == 1:
+            if self.dtype == torch.float32:
+                _hip.logits_to_prob(logits, out=dst)                 # D2 (emp_logits_to_prob)
+            elif nc == 1:
                 torch.sigmoid(logits, out=dst)
             else:
                 torch.softmax(logits, dim=1, out=dst)

@@ -56,6 +56,7 @@ SIGNATURES = {
     'emp_pointwise_out_nhwc': (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),
     'emp_bn_relu_maxpool_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'emp_stem_conv7_bn_relu_maxpool': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    'emp_logits_to_prob': (_I, [_P, _I, _I, _L, _P, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
@@ -668,6 +669,21 @@ def bn_relu_maxpool_nhwc(x, scale, shift):
     call('emp_bn_relu_maxpool_nhwc', x.data_ptr(), _ptr(scale), _ptr(shift), N, H, W, C, y.data_ptr(), stream(),
          alg_bytes=4 * (x.numel() + y.numel()))
     return y
+
+
+def logits_to_prob(logits, out=None):
+    """sigmoid (C == 1) / softmax over dim 1 (C > 1) of (N,C,H,W) fp32 CUDA logits (emp_logits_to_prob).  `out`: optional
+    contiguous (N,C,H,W) fp32 destination (may be `logits` itself)."""
+    require_gpu()
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 4
+    x = logits if logits.is_contiguous() else logits.contiguous()
+    N, C, H, W = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.is_cuda and out.dtype == torch.float32 and out.shape == x.shape and out.is_contiguous()
+    if x.numel():
+        call('emp_logits_to_prob', x.data_ptr(), N, C, H * W, out.data_ptr(), stream(), alg_bytes=8 * x.numel())
+    return out
 
 
 def stem_conv7_bn_relu_maxpool(x, w_tc, scale, shift):

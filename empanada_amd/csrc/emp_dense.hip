@@ -471,3 +471,60 @@ extern "C" int emp_bn_relu_maxpool_nhwc(const float *x, const float *scale, cons
     EMP_CHECK_LAUNCH("emp_bn_relu_maxpool_nhwc");
     return EMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// D2: logits_to_prob (engines.py:22-30): sigmoid for one channel, softmax over the channel axis otherwise, planar
+// (N, C, HW) fp32.  One streaming pass; every lane owns 4 consecutive pixels (float4 per channel plane).
+template <int VEC>
+__global__ __launch_bounds__(256) void logits_to_prob_kernel(const float *__restrict__ x, int C, int64_t HW, int64_t total,
+                                                             float *__restrict__ y)
+{
+    // total = N * HW / VEC work items; item i covers pixels [VEC * (i % (HW / VEC)), +VEC) of image i / (HW / VEC)
+    const int64_t per = HW / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / per, p = (i - n * per) * VEC;
+        const float *xp = x + n * C * HW + p;
+        float *yp = y + n * C * HW + p;
+        if (C == 1) {
+            float v[VEC];
+            if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4 *>(xp); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+            else v[0] = xp[0];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v[e])));
+            if constexpr (VEC == 4) *reinterpret_cast<float4 *>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            else yp[0] = v[0];
+        } else {
+            float m[VEC], sum[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { m[e] = -INFINITY; sum[e] = 0.f; }
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], xp[c * HW + e]);
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sum[e] = __fadd_rn(sum[e], expf(__fsub_rn(xp[c * HW + e], m[e])));
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) yp[c * HW + e] = __fdiv_rn(expf(__fsub_rn(xp[c * HW + e], m[e])), sum[e]);
+        }
+    }
+}
+
+extern "C" int emp_logits_to_prob(const float *logits, int N, int C, int64_t HW, float *prob, void *stream)
+{
+    EMP_REQUIRE(logits && prob, "logits_to_prob: null pointer");
+    EMP_REQUIRE(N >= 0 && C >= 1 && C <= 64 && HW > 0, "logits_to_prob: bad shape");
+    if (N == 0) return EMP_OK;
+    const bool vec = HW % 4 == 0 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(prob)) & 15) == 0;
+    if (vec && C == 1) {
+        const int64_t total = (int64_t)N * (HW / 4);
+        hipLaunchKernelGGL(logits_to_prob_kernel<4>, dim3(emp_grid(total, 256, 16384)), dim3(256), 0, emp_stream(stream),
+                           logits, C, HW, total, prob);
+    } else {
+        const int64_t total = (int64_t)N * HW;
+        hipLaunchKernelGGL(logits_to_prob_kernel<1>, dim3(emp_grid(total, 256, 16384)), dim3(256), 0, emp_stream(stream),
+                           logits, C, HW, total, prob);
+    }
+    EMP_CHECK_LAUNCH("emp_logits_to_prob");
+    return EMP_OK;
+}

@@ -24,7 +24,10 @@ __all__ = ['PanopticDeepLabEngine', 'PanopticDeepLabEngine3d', 'PanopticDeepLabR
 
 @torch.no_grad()
 def logits_to_prob(logits):
-    """engines.py:22-30"""
+    """engines.py:22-30.  fp32 logits on the GPU go through emp_logits_to_prob (D2); anything else (a host tensor, a
+    half-precision model) keeps the library call the reference makes."""
+    if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 4:
+        return _hip.logits_to_prob(logits)
     if logits.size(1) > 1:
         return F.softmax(logits, dim=1)
     return torch.sigmoid(logits)

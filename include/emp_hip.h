@@ -234,6 +234,15 @@ int emp_bn_relu_maxpool_nhwc(const float *x, const float *scale, const float *sh
 int emp_stem_conv7_bn_relu_maxpool(const float *x, const float *w_tc, const float *scale, const float *shift,
                                    int N, int H, int W, float *y, void *stream);
 
+/* ---- D2: logits -> probabilities ---------------------------------------------------------------------------
+ * replaces logits_to_prob                                         empanada/inference/engines.py:22-30
+ * C == 1: prob = 1 / (1 + expf(-x)) (negation exact, add and divide separate fp32 roundings);
+ * C  > 1: softmax over the channel axis: m = max_c x_c, e_c = expf(x_c - m), s = sum of e_c in ascending c from +0,
+ *         prob_c = e_c / s.  expf is the device library's (torch's GPU and CPU kernels use their own: results agree within
+ *         2 ulp, the hardening decision `p >= thr` on logits within 1e-3 of logit(thr) in all but a few of 2 * 10^6
+ *         cases -- tests/test_pipeline_gpu.py).  logits, prob: planar (N, C, HW) fp32; may alias.               */
+int emp_logits_to_prob(const float *logits, int N, int C, int64_t HW, float *prob, void *stream);
+
 /* ---- P1 + P2: recursive median over a resident stack, fused with hardening ----------------
  * replaces _MedianQueue.get_next/get_median/end   empanada/inference/engines.py:47-90
  *          _harden_seg / harden_seg               engines.py:114-121, inference/patterns.py:242-251

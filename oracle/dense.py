@@ -219,6 +219,21 @@ def bn_relu_maxpool_nhwc(x_nhwc, scale, shift):
     return out
 
 
+def logits_to_prob(logits):
+    """logits_to_prob (empanada/inference/engines.py:22-30) in the operation order of include/emp_hip.h (D2), numpy fp32
+    (np.exp on float32 = the host libm's expf: the HIP kernel's device expf may differ in the last place)"""
+    x = np.asarray(logits, dtype=np.float32)
+    one = np.float32(1)
+    if x.shape[1] == 1:
+        return (one / (one + np.exp(-x))).astype(np.float32)
+    m = x.max(axis=1, keepdims=True)
+    e = np.exp((x - m).astype(np.float32)).astype(np.float32)
+    s = np.zeros_like(m)
+    for c in range(x.shape[1]):
+        s = (s + e[:, c:c + 1]).astype(np.float32)
+    return (e / s).astype(np.float32)
+
+
 def stem_conv7_bn_relu_maxpool(x_nhw, w_tc, scale, shift):
     """The ResNet stem (encoders/resnet.py:186-188,217-222: conv1 7x7 / 2 -> bn1 -> relu -> maxpool 3x3 / 2) on a
     one-channel image x (N,H,W): convolution as one fmaf chain per output over the 49 taps in raster order (plain C),

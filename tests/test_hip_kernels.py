@@ -585,6 +585,42 @@ def test_gconv3x3_bn_act_nhwc(hip, cfg):
     np.testing.assert_array_equal(got0.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp0.view(np.uint32))
 
 
+@pytest.mark.parametrize('shape', [(2, 1, 64, 64), (1, 1, 37, 45), (3, 5, 32, 48), (2, 3, 17, 9), (1, 16, 8, 8), (0, 1, 4, 4)])
+def test_logits_to_prob_kernel(hip, shape):
+    """emp_logits_to_prob (D2, engines.py:22-30): against the oracle (same operation order, host expf) and against
+    torch's own sigmoid / softmax on the GPU and on the CPU, all within 4 ulp; softmax rows sum to 1 within 3e-7; in
+    place (prob aliasing logits) gives the same bits; odd sizes take the scalar path."""
+    from oracle import dense as OD
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g) * 4
+    got = hip.logits_to_prob(x.cuda())
+    assert got.shape == x.shape
+    if x.numel() == 0:
+        return
+    ref_gpu = (torch.sigmoid(x.cuda()) if shape[1] == 1 else torch.softmax(x.cuda(), dim=1)).cpu()
+    ref_cpu = torch.sigmoid(x) if shape[1] == 1 else torch.softmax(x, dim=1)
+    exp = torch.from_numpy(OD.logits_to_prob(x.numpy()))
+
+    def ulps(a, b):
+        return (a.view(torch.int32) - b.view(torch.int32)).abs().max().item()
+
+    g_cpu = got.cpu()
+    # sigmoid: a few ulp (tiny probabilities p ~ exp(x) inherit the last-place differences of three exp
+    # implementations: device library, host libm, ATen's vectorised Sleef); softmax: the quotient of two rounded sums --
+    # compared absolutely (probabilities <= 1)
+    if shape[1] == 1:
+        u = (ulps(g_cpu, exp), ulps(g_cpu, ref_gpu), ulps(g_cpu, ref_cpu))
+        assert max(u) <= 4, u
+    else:
+        for r in (exp, ref_gpu, ref_cpu):
+            assert (g_cpu - r).abs().max().item() <= 3e-7
+        assert (g_cpu.sum(dim=1) - 1).abs().max().item() <= 3e-7
+        assert int((g_cpu.argmax(dim=1) != ref_cpu.argmax(dim=1)).sum()) == 0
+    y = x.cuda().clone()
+    hip.logits_to_prob(y, out=y)
+    assert torch.equal(y, got)
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 64), (1, 37, 45), (3, 130, 70), (1, 7, 9), (2, 256, 320), (1, 1, 1)])
 def test_stem_conv7_bn_relu_maxpool(hip, shape):
     """emp_stem_conv7_bn_relu_maxpool (D9): bit-exact against the oracle (fma chain over the 49 taps in raster order,
