@@ -188,6 +188,22 @@ class MedianQueue:
         return list(self.median_queue)[self.mid_idx + 1:]
 
 
+def post_slice(o, *, thing_list, label_divisor=1000, stuff_area=64, void_label=0, nms_threshold=0.1, nms_kernel=7,
+               confidence_thr=0.5, coarse_boundaries=True, render=True):
+    """What a 3d engine does with one item leaving the median queue: PanopticDeepLabRenderEngine3d.postprocess
+    (engines.py:344-349 -> :277-292, cropped to the item's size) or PanopticDeepLabEngine3d (engines.py:209-219)."""
+    if render:
+        cells = get_instance_cells(o['ctr_hmp'], o['offsets'], nms_threshold, nms_kernel, coarse_boundaries, 1)
+        sem = harden_seg(o['sem'], confidence_thr)[0]
+        pan = get_panoptic_seg(sem, cells, label_divisor, thing_list, stuff_area, void_label)
+        h, w = o['size']
+        return pan[..., :h, :w]
+    sem = harden_seg(o['sem'], confidence_thr)
+    pan, _ = get_panoptic_segmentation(sem, o['ctr_hmp'], o['offsets'], thing_list, label_divisor,
+                                       stuff_area, void_label, nms_threshold, nms_kernel)
+    return pan
+
+
 def engine3d_stack(sem_probs, ctr_hmps, offsets, *, thing_list, label_divisor=1000, stuff_area=64,
                    void_label=0, nms_threshold=0.1, nms_kernel=7, confidence_thr=0.5,
                    median_kernel_size=3, coarse_boundaries=True, render=True, sizes=None):
@@ -201,19 +217,9 @@ def engine3d_stack(sem_probs, ctr_hmps, offsets, *, thing_list, label_divisor=10
     """
     q = MedianQueue(median_kernel_size)
     outs = []
-
-    def post(o):
-        if render:
-            cells = get_instance_cells(o['ctr_hmp'], o['offsets'], nms_threshold, nms_kernel,
-                                       coarse_boundaries, 1)
-            sem = harden_seg(o['sem'], confidence_thr)[0]
-            pan = get_panoptic_seg(sem, cells, label_divisor, thing_list, stuff_area, void_label)
-            h, w = o['size']
-            return pan[..., :h, :w]
-        sem = harden_seg(o['sem'], confidence_thr)
-        pan, _ = get_panoptic_segmentation(sem, o['ctr_hmp'], o['offsets'], thing_list, label_divisor,
-                                           stuff_area, void_label, nms_threshold, nms_kernel)
-        return pan
+    kw = dict(thing_list=thing_list, label_divisor=label_divisor, stuff_area=stuff_area, void_label=void_label,
+              nms_threshold=nms_threshold, nms_kernel=nms_kernel, confidence_thr=confidence_thr,
+              coarse_boundaries=coarse_boundaries, render=render)
 
     for t in range(len(sem_probs)):
         size = sizes[t] if sizes is not None else tuple(np.asarray(sem_probs[t]).shape[-2:])
@@ -221,7 +227,7 @@ def engine3d_stack(sem_probs, ctr_hmps, offsets, *, thing_list, label_divisor=10
                    'offsets': _f32(offsets[t]), 'size': size})
         o = q.get_next(['sem'])
         if o is not None:
-            outs.append(post(o))
+            outs.append(post_slice(o, **kw))
     for o in q.end():
-        outs.append(post(o))
+        outs.append(post_slice(o, **kw))
     return outs

@@ -1,6 +1,5 @@
 """GPU: BASELINE.json configs[1] at its full size (256 x 512 x 512 stack, ks = 7, full-resolution heads) through the
-post-processing path, checked with size-independent properties (the oracle finishes only a sub-stack in seconds, and is
-compared there):
+post-processing path, checked with size-independent properties AND against the oracle on the whole stack:
 
   * run-table round trip: painting the run table of the panoptic stack with each run's own value reproduces the
     thing voxels of the stack exactly (encode -> decode);
@@ -8,7 +7,7 @@ compared there):
   * the label-propagation chain only merges: every final object is a union of components, its voxel count is the sum
     of their areas, and objects of the planted ground truth are recovered after the size / span filters (PQ >= 0.93 against the planted labels, >= 97 % matched);
   * determinism: a second pass is bit-identical;
-  * a sub-stack (first 24 slices) equals the oracle bit for bit, ids included;
+  * the whole stack equals the oracle bit for bit: every panoptic slice and the tracked volume, ids included;
   * two virtual ranks with a one-slice halo (the multi-GPU decomposition) give the single-rank volume.
 """
 import os
@@ -91,19 +90,24 @@ def test_chain_volume_properties_and_determinism(stack):
     assert torch.equal(vol2.view(torch.int32), vol.view(torch.int32))
 
 
-def test_substack_equals_oracle(stack):
+def test_whole_stack_equals_oracle(stack):
+    """configs[1] at its FULL size against the oracle, bit for bit: all 256 panoptic slices (median recursion, centres,
+    grouping, fusion) and the tracked + filtered uint32 volume, instance ids included.  The oracle's per-pixel stages are
+    spread over the host cores (oracle/pipeline.py); matching and tracking run in the reference's serial order."""
     bench, heads, pan, _ = stack
-    from oracle import postprocess as OP
-    n = 24
-    sub = {k: v[:n].cpu().numpy() for k, v in heads.items()}
-    pans = OP.engine3d_stack([sub['sem'][t:t + 1] for t in range(n)], [sub['ctr_hmp'][t:t + 1] for t in range(n)],
-                             [sub['offsets'][t:t + 1] for t in range(n)], coarse_boundaries=False, render=True,
-                             sizes=[(S, S)] * n, **bench.ENGINE)
-    m = bench.ENGINE['median_kernel_size'] // 2
-    # the recursive median looks m slices ahead: the first n - m slices of the sub-stack are those of the full stack
-    got = pan[:n - m].cpu().numpy().astype(np.int64)
-    exp = np.stack([np.asarray(p).squeeze() for p in pans[:n - m]]).astype(np.int64)
-    np.testing.assert_array_equal(got, exp)
+    from empanada_amd.inference import sharded
+    from oracle import pipeline as PL
+    cpu = {k: v.cpu().numpy() for k, v in heads.items()}
+    pans, exp_vol, n_inst = PL.stack_volume(cpu, bench.ENGINE, bench.MATCH, bench.FILTERS, labels=[1],
+                                            workers=min(16, os.cpu_count() or 1))
+    assert len(pans) == D and n_inst > 100
+    got = pan.cpu().numpy()
+    for t in range(D):
+        np.testing.assert_array_equal(got[t].astype(np.int64), pans[t], err_msg=f'slice {t}')
+    vol = sharded.sharded_stack_volume(pan, [1], [1], bench.ENGINE['label_divisor'], min_size=bench.FILTERS['min_size'],
+                                       min_span=bench.FILTERS['min_span'], **bench.MATCH)
+    np.testing.assert_array_equal(vol.view(torch.int32).cpu().numpy().astype(np.uint32), exp_vol)
+    assert len(np.unique(exp_vol)) - 1 == n_inst
 
 
 def test_two_virtual_ranks_equal_single_rank(stack):
@@ -135,7 +139,7 @@ def test_two_virtual_ranks_equal_single_rank(stack):
 
 
 # ------------------------------------------------------------------------------------------------ configs[2]: 512^3
-def test_orthoplane_512_cubed_properties_and_oracle_subvolume(tmp_path):
+def test_orthoplane_512_cubed_properties_and_whole_volume_oracle(tmp_path):
     """BASELINE configs[2] at its full size through bench.py's own orthoplane path (three planes -> device-resident
     trackers -> consensus on tables -> fill -> zarr), checked with size-independent properties:
       * conservation: every consensus instance paints exactly the voxels its table says (minus what later instances
@@ -143,16 +147,12 @@ def test_orthoplane_512_cubed_properties_and_oracle_subvolume(tmp_path):
       * the planted ground truth is recovered (PQ against the planted labels);
       * determinism: a second pass is bit-identical;
       * encode -> write -> read: the zarr array read back equals the device volume;
-    and, on a 96^3 corner sub-volume (what the oracle finishes in seconds), the consensus volume equals the oracle's
-    bit for bit, ids included."""
+    and the WHOLE consensus volume equals the oracle's bit for bit, ids included (oracle/pipeline.py: about a minute
+    on the box's host cores)."""
     import bench
-    from empanada_amd import synthetic as SY
     from empanada_amd.evaluation import volume_pq
     from empanada_amd.zarr_utils import SlabWriter, ZarrV2Group, open_zarr
-    from oracle import consensus as OC
-    from oracle import postprocess as OP
-    from oracle import rle_ops as OR
-    from oracle import rle_seg as OS
+    from oracle import pipeline as PL
     S2 = 512
     truth = {}
     stacks, heads, n_obj, _ = bench.build_inputs_ortho(S2, torch.device('cuda'), labels_out=truth)
@@ -190,41 +190,21 @@ def test_orthoplane_512_cubed_properties_and_oracle_subvolume(tmp_path):
         off = pt.offsets().cpu().numpy()
         cs = np.concatenate([[0], np.cumsum(pt.ln[:pt.n_runs].cpu().numpy())])
         np.testing.assert_array_equal(cs[off[1:]] - cs[off[:-1]], pt.inst_area)
-    pq, n_gt, n_pred, n_match = volume_pq(truth['lab'].astype(np.uint32), v.cpu().numpy().astype(np.uint32))
+    got_vol = v.cpu().numpy().astype(np.uint32)
+    pq, n_gt, n_pred, n_match = volume_pq(truth['lab'].astype(np.uint32), got_vol)
     assert pq > 0.9 and n_match >= 0.95 * n_gt
     # zarr round trip
     back = open_zarr(ds.path)
     for z in (0, 1, S2 // 2, S2 - 1):
-        np.testing.assert_array_equal(back[z], v[z].cpu().numpy().astype(np.uint32))
+        np.testing.assert_array_equal(back[z], got_vol[z])
+    cpu = {a: {k: t.cpu().numpy() for k, t in heads[a].items()} for a in heads}
     del heads, vol, vol2, vols, vols2, planes
     torch.cuda.empty_cache()
 
-    # ---- corner sub-volume against the oracle
-    n = 96
-    shape = (n, n, n)
-    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321)
-    sub = {a: SY.planted_heads(lab, cls, a, seed=99) for a in ('xy', 'xz', 'yz')}
-    div, things = bench.ENGINE['label_divisor'], [1]
-    trackers = OS.create_axis_trackers(['xy', 'xz', 'yz'], [1], div, shape)
-    for axis in ('xy', 'xz', 'yz'):
-        sem, ctr, off = (sub[axis][k].numpy() for k in ('sem', 'ctr_hmp', 'offsets'))
-        pans = OP.engine3d_stack([sem[t:t + 1] for t in range(n)], [ctr[t:t + 1] for t in range(n)],
-                                 [off[t:t + 1] for t in range(n)], coarse_boundaries=False, render=True, **bench.ENGINE)
-        pans = [p.squeeze() for p in pans]
-        matchers = OS.create_matchers(things, div, 0.25, 0.25)
-        stack = OS.forward_matching(pans, matchers, [1], div, things)
-        for idx, rs in OS.backward_matching(stack, matchers, n):
-            OS.update_trackers(rs, idx, trackers[axis])
-        OS.finish_tracking(trackers[axis])
-        for tr in trackers[axis]:
-            OS.remove_small_objects(tr, bench.FILTERS['min_size'])
-            OS.remove_pancakes(tr, bench.FILTERS['min_span'])
-    con = OC.create_instance_consensus([t for a in ('xy', 'xz', 'yz') for t in trackers[a]], 2, 0.75, False)
-    OS.remove_small_objects(con, bench.FILTERS['min_size'])
-    OS.remove_pancakes(con, bench.FILTERS['min_span'])
-    exp = OR.numpy_fill_instances(np.zeros(shape, np.uint32), con.instances)
-    dev = {a: {k: t.cuda().contiguous() for k, t in sub[a].items()} for a in sub}
-    _, gots, _ = bench.postprocess_planes(dev, shape, None, {})
-    got = gots[1]
-    assert exp.max() >= 3
-    np.testing.assert_array_equal(got.view(torch.int32).cpu().numpy().astype(np.uint32), exp)
+    # ---- the WHOLE 512^3 consensus volume against the oracle, ids included
+    tm = {}
+    exp, n_exp, _ = PL.orthoplane_volume(cpu, (S2,) * 3, bench.ENGINE, bench.MATCH, bench.FILTERS, bench.CONSENSUS,
+                                         labels=[1], workers=min(16, os.cpu_count() or 1), timers=tm)
+    print('oracle 512^3:', {k: round(t, 1) for k, t in tm.items()})
+    assert n_exp == n_found
+    np.testing.assert_array_equal(got_vol, exp[1])

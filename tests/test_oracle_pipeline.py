@@ -68,3 +68,37 @@ def test_pipeline_matches_reference():
             np.testing.assert_array_equal(vols[cid], g[f'p{i}_vol{cid}'])
             if cid == 1:
                 assert vols[cid].max() >= 3, "planted workload should produce several instances"
+
+
+def test_pipeline_driver_serial_and_parallel_match_reference():
+    """oracle/pipeline.py (the driver the full-size GPU tests and bench.py's cpu_baseline use), serial and with the
+    per-pixel stages spread over worker processes, against the reference's own consensus volumes and panoptic slices."""
+    from oracle import pipeline as PL
+    g = load_golden('pipeline')
+    for i in range(int(g['n'])):
+        C, ks, _, head_seed = (int(x) for x in g[f'p{i}_par'])
+        lab, cls = g[f'p{i}_lab'], g[f'p{i}_cls']
+        thing = [1] if C == 1 else list(range(1, C))
+        labels = [1] if C == 1 else list(range(1, C + 1))
+        engine = dict(thing_list=thing, label_divisor=1000, stuff_area=16, void_label=0, nms_threshold=0.1, nms_kernel=7,
+                      confidence_thr=0.5, median_kernel_size=ks)
+        heads = {a: {k: v.numpy() for k, v in SY.planted_heads(lab, cls, a, n_classes=C, seed=head_seed,
+                                                                coarse=False).items()} for a in PL.AXES}
+        for workers in (1, 3):
+            vols, n_inst, _ = PL.orthoplane_volume(heads, lab.shape, engine, dict(merge_iou_thr=0.25, merge_ioa_thr=0.25),
+                                                   dict(min_size=100, min_span=3),
+                                                   dict(pixel_vote_thr=2, cluster_iou_thr=0.75, bypass=False),
+                                                   labels=labels, workers=workers)
+            for cid in labels:
+                np.testing.assert_array_equal(vols[cid], g[f'p{i}_vol{cid}'], err_msg=f'{i} class {cid} workers {workers}')
+        h = heads['xz']
+        pans, _ = PL.plane_pans(h['sem'], h['ctr_hmp'], h['offsets'], engine, labels=labels, workers=3)
+        np.testing.assert_array_equal(np.stack(pans), g[f'p{i}_xz_pan'])
+    # a stack shorter than the median kernel loses its tail in both forms (engines.py:68-90)
+    short = {k: v[:4] for k, v in heads['xy'].items()}
+    e7 = dict(engine, median_kernel_size=7)
+    a, _ = PL.plane_pans(short['sem'], short['ctr_hmp'], short['offsets'], e7, labels=labels, workers=1)
+    b, _ = PL.plane_pans(short['sem'], short['ctr_hmp'], short['offsets'], e7, labels=labels, workers=2)
+    assert len(a) == len(b) == len(PL.emitted_slices(4, 7)) < 4
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_instances_equal, load_golden, unpack_instances
+from conftest import assert_instances_equal, dense_tol, load_golden, unpack_instances
 from empanada_amd import synthetic as SY
 
 pytestmark = pytest.mark.gpu
@@ -282,7 +282,8 @@ def test_model_forward_matches_cpu_within_tolerance():
     from empanada_amd.models import PanopticDeepLab, prepare_for_inference, synthesize_weights
     torch.manual_seed(0)
     m = synthesize_weights(PanopticDeepLab(encoder='resnet50', num_classes=1)).eval()
-    # damp the synthetic head scale so that logits are O(1) like a trained model's
+    # damp the synthetic head scale (He weights are hot): logits come out O(0.05), so the bound below is RELATIVE to
+    # the head's own |ref|_inf -- 1e-4 of full scale, no absolute floor a sloppy kernel could hide under
     with torch.no_grad():
         for head in (m.semantic_head, m.ins_center, m.ins_xy):
             head.head[1].weight.mul_(1e-3)
@@ -294,7 +295,7 @@ def test_model_forward_matches_cpu_within_tolerance():
     for k in ref:
         scale = float(ref[k].abs().max())
         err = float((out[k].float().cpu() - ref[k]).abs().max())
-        assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (k, err, scale)
+        assert err <= dense_tol(scale), (k, err, scale)
 
 
 @pytest.mark.parametrize('force', ['direct', 'wino', 'wino_sep', 'wino4', 'wino3', 'tuned'])
@@ -331,7 +332,7 @@ def test_model_forward_with_hip_convolutions(force):
     for k in ref:
         scale = float(ref[k].abs().max())
         err = float((out[k].float().cpu() - ref[k]).abs().max())
-        assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (force, k, err, scale)
+        assert err <= dense_tol(scale), (force, k, err, scale)
 
 
 @pytest.mark.parametrize('force', ['hand_written', 'tuned'])
@@ -374,7 +375,7 @@ def test_regnety_forward_with_hip_convolutions(force):
     for k in ref:
         scale = float(ref[k].abs().max())
         err = float((out[k].float().cpu() - ref[k]).abs().max())
-        assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (force, k, err, scale)
+        assert err <= dense_tol(scale), (force, k, err, scale)
 
 
 def test_graphed_forward_replays_the_model():
@@ -438,9 +439,9 @@ def test_model_forward_large_batch_equals_small_batches(force):
             small = g(x[s:s + 16])
             for k, v in small.items():
                 ref = v.float().cpu()
-                scale = max(1.0, float(ref.abs().max()))
+                scale = float(ref.abs().max())
                 err = float((big[k][s:s + 16] - ref).abs().max())
-                assert err <= 1e-4 * scale, (force, k, s, err, scale)
+                assert err <= dense_tol(scale), (force, k, s, err, scale)
 
 
 @pytest.mark.parametrize('encoder,force', [('resnet50', 'direct'), ('resnet50', 'tuned'), ('regnety_6p4gf', 'direct')])
@@ -474,7 +475,7 @@ def test_bifpn_forward_with_hip_convolutions(encoder, force):
     for k in ref:
         scale = float(ref[k].abs().max())
         err = float((out[k].float().cpu() - ref[k]).abs().max())
-        assert err <= 1e-4 * max(scale, 1.0) + 1e-4, (encoder, force, k, err, scale)
+        assert err <= dense_tol(scale), (encoder, force, k, err, scale)
 
 
 def test_sharded_path_world1_equals_tracker_path():
