@@ -225,16 +225,20 @@ class Pipeline:
         """True if the next forward() call replays captured graphs (cheap to queue far ahead)"""
         return self.graphed is not None and self.dtype == torch.float32 and self.dense_profile_left == 0
 
-    def adopt_choices_of_rank0(self):
-        """the tuner's timings differ slightly from GPU to GPU; all ranks take rank 0's choice per call site so that a
-        slice's logits do not depend on the rank that computed it"""
+    def tune_on_rank0(self, size, rank, save=None, load=None):
+        """N ranks: only rank 0 runs the search (MIOpen's find + the per-site timing loop, ~50 s); the others wait for
+        its choice per call site and adopt it -- a slice's logits must not depend on the rank that computed it, and
+        N - 1 redundant searches whose results are thrown away only lengthen the warm-up."""
         import torch.distributed as dist
         from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
         sites = [(n, m) for n, m in self.model.named_modules() if isinstance(m, FusedConvBNAct)]
-        box = [{n: m.impl for n, m in sites}]
+        if rank == 0:
+            self.tune(size, save, load)
+        box = [({n: m.impl for n, m in sites}, self.tuned) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
+        choice, self.tuned = box[0]
         for n, m in sites:
-            m.impl = box[0].get(n, m.impl)
+            m.impl = choice.get(n, m.impl)
 
     @torch.no_grad()
     def forward(self, dv, axis='xy', lo=0, hi=None):
@@ -332,6 +336,31 @@ def build_inputs(D, S, device, seed_offset=0, things=1):
     return vol, heads, int(cls.shape[0] - 1)
 
 
+def shared_host_inputs(shape, rank, things):
+    """N ranks of one node: rank 0 draws the synthetic EM volume and the planted label volume ONCE into files under
+    /dev/shm, the others map them (the draws are seeded, so this changes nothing but the host time and memory: eight
+    ranks each drawing 1024^3 labels on the same host cores would take eight times the CPU for identical arrays)."""
+    import torch.distributed as dist
+    from empanada_amd import synthetic as SY
+    base = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
+    d = os.path.join(base, f'emp_bench_inputs_{os.environ.get("MASTER_PORT", "0")}')
+    if rank == 0:
+        os.makedirs(d, exist_ok=True)
+        lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321, n_classes=things)
+        np.save(os.path.join(d, 'lab.npy'), lab)
+        np.save(os.path.join(d, 'cls.npy'), cls)
+        np.save(os.path.join(d, 'em.npy'), SY.em_volume(shape, seed=1234))
+    dist.barrier()
+    em = np.load(os.path.join(d, 'em.npy'), mmap_mode='r')
+    lab = np.load(os.path.join(d, 'lab.npy'), mmap_mode='r')
+    cls = np.load(os.path.join(d, 'cls.npy'))
+    em, lab = np.array(em), np.array(lab)            # private copies: the files go away below
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
+    return em, lab, cls
+
+
 def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None, things=1):
     """cubic volume shared by all ranks; every rank holds the whole uint8 EM volume (1 GiB at 1024^3; each plane is a
     strided view of it) and the planted heads of its own contiguous block of slices per plane"""
@@ -341,13 +370,17 @@ def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None, things=1):
     shape = (S, S, S)
     b = shard_bounds(S, world)
     lo, hi = int(b[rank]), int(b[rank + 1])
-    box = {}
-    t = threading.Thread(target=lambda: box.update(lab=SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321,
-                                                                         n_classes=things)))
-    t.start()                                      # numpy on the host, while the EM volume is drawn and uploaded
-    dv = DeviceVolume(SY.em_volume(shape, seed=1234), NORM['mean'], NORM['std'], 16, device)
-    t.join()
-    lab, cls = box['lab']
+    if world > 1:
+        em, lab, cls = shared_host_inputs(shape, rank, things)
+        dv = DeviceVolume(em, NORM['mean'], NORM['std'], 16, device)
+    else:
+        box = {}
+        t = threading.Thread(target=lambda: box.update(lab=SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24,
+                                                                             seed=4321, n_classes=things)))
+        t.start()                                  # numpy on the host, while the EM volume is drawn and uploaded
+        dv = DeviceVolume(SY.em_volume(shape, seed=1234), NORM['mean'], NORM['std'], 16, device)
+        t.join()
+        lab, cls = box['lab']
     if labels_out is not None:
         labels_out.update(lab=lab, cls=cls)
     lab_dev = torch.from_numpy(lab.view(np.int16)).to(device)
@@ -520,9 +553,10 @@ def main_orthoplane(args, device, rank, world):
     log(f'inputs ready ({n_obj} planted objects)')
     pipe = Pipeline(args, device)
     if not args.no_tune:
-        pipe.tune(S, args.save_tune, args.load_tune)
         if world > 1:
-            pipe.adopt_choices_of_rank0()            # every rank runs the same kernels: slice-independent numerics
+            pipe.tune_on_rank0(S, rank, args.save_tune, args.load_tune)   # every rank runs the same kernels
+        else:
+            pipe.tune(S, args.save_tune, args.load_tune)
     shape3d = (S, S, S)
     from empanada_amd.inference.sharded import shard_bounds
     from empanada_amd.zarr_utils import SlabWriter, ZarrV2Group, open_zarr
@@ -565,10 +599,13 @@ def main_orthoplane(args, device, rank, world):
     log(f'timed {args.steps} steps in {dt:.2f}s')
     prof, _hip.PROFILE = _hip.PROFILE, None
     _hip.PROFILE_SKIP.clear()
+    per_rank = [dt]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = torch.zeros((world,), dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(allt, t)
+        per_rank = [float(v) for v in allt.cpu()]
+        dt = max(per_rank)                           # the job is as slow as its slowest rank
     for w in writer.values():
         w.close()
     if rank != 0:
@@ -589,6 +626,9 @@ def main_orthoplane(args, device, rank, world):
         'metric': METRIC,
         'value': round(float(S) ** 3 * args.steps / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
+        'ms_per_step_per_rank': [round(v / args.steps * 1e3, 2) for v in per_rank],
+        'world_size': dist.get_world_size() if world > 1 else 1,
+        'backend': dist.get_backend() if world > 1 else None,
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f32' if args.dtype == 'fp32' else args.dtype, 'data': 'synthetic',
         'config': {'workload': f'orthoplane (xy/xz/yz) inference + instance consensus, {S}^3 uint8 volume '
@@ -596,7 +636,10 @@ def main_orthoplane(args, device, rank, world):
                                f'C={1 if len(LABELS) == 1 else len(LABELS) + 1} fp32 '
                                f'forward on every slice of every plane + HIP post-processing on planted heads '
                                f'(ks=7, full-res heads), {n_obj} planted objects, slices of every plane sharded over '
-                               f'{world} rank(s)',
+                               f'{world} rank(s); labelled uint32 volume copied to the host and written as a zarr v2 '
+                               f'array (chunks (1,Y,X), uncompressed) under {os.path.dirname(out_dir)}'
+                               + (' (tmpfs: the write costs memory bandwidth, not disk)' if out_dir.startswith('/dev/shm')
+                                  else ''),
                    'mode': 'orthoplane', 'size': S, 'objects_found': int(n_found), 'output': out_check,
                    'batch': pipe.slices_per_call(S, S)},
         'breakdown': {'stages_s_per_step': {k: round(v / args.steps, 4) for k, v in stages.items()},

@@ -8,9 +8,10 @@ CC -> RLE -> matching for the whole stack.
 What this module does instead (MI355X-first; no rank is special, nothing is pickled, no pixels through the host):
   1. every rank runs the model on its own contiguous block of slices (no communication);
   2. the recursive median (serial in z by definition, engines.py:68-90) is handed over from rank to rank: rank r
-     receives the last ks//2 FILTERED probability slices of rank r-1 and the first ks//2 RAW slices of rank r+1
-     (point-to-point over xGMI, 4 MiB per slice at 1024^2), filters its block and passes its own tail on.  The chain
-     is serial but each link costs ~0.2 ms; memory stays O(block);
+     uses the last ks//2 FILTERED probability slices of rank r-1 and the first ks//2 RAW slices of rank r+1 (one
+     all-gather of the raw heads + world-1 small broadcasts of filtered tails: collectives on one communicator only),
+     filters its block and passes its own tail on.  The chain is serial but each link costs ~0.2 ms; memory stays
+     O(block);
   3. centres, grouping, fusion, runs, connected components: local, on the rank's own slices;
   4. a one-slice halo (first label slice of the next rank) gives the overlaps across block borders;
   5. the O(#components) tables are all-gathered as ONE padded int64 tensor and EVERY rank runs the (deterministic)
@@ -232,15 +233,15 @@ def _all_gather_cat(t, group=None):
     return out
 
 
-def _send(t, dst, group):
-    dist.send(t.contiguous().cpu() if _staged(t, group) else t.contiguous(), dst, group=group)
-
-
-def _recv(shape, dtype, device, src, group):
-    staged = device.type == 'cuda' and dist.get_backend(group) == 'gloo'
-    buf = torch.empty(shape, dtype=dtype, device='cpu' if staged else device)
-    dist.recv(buf, src, group=group)
-    return buf.to(device)
+def _broadcast(t, src, group):
+    """broadcast of a device tensor in place (staged through the host under gloo)"""
+    if _staged(t, group):
+        h = t.contiguous().cpu()
+        dist.broadcast(h, src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src, group=group)
+    return t
 
 
 def median_handover(prob_local, ks, thr, group=None, median=None):
@@ -248,7 +249,15 @@ def median_handover(prob_local, ks, thr, group=None, median=None):
     result: out[t] = median(out[t-m .. t-1], x[t .. t+m]) (engines.py:68-84), first / last m slices of the AXIS raw.
     The kernel passes the first m slices of whatever stack it is given through unchanged and uses them as history, so
     prepending rank r-1's last m filtered slices (and appending rank r+1's first m raw ones) reproduces the recursion
-    bit for bit.  Block sizes may differ; every block must hold at least m slices.  Returns sem (D_local, H, W) u8."""
+    bit for bit.  Block sizes may differ; every block must hold at least m slices.  Returns sem (D_local, H, W) u8.
+
+    Communication is collectives on the group's one communicator only (no point-to-point pairs, whose communicators
+    RCCL would create lazily inside the timed loop, and no ordering between pairs to reason about):
+      * raw halo: ONE all-gather of every rank's first m slices (world x m x C x H x W fp32: 96 MiB at 1024^2, N = 8);
+        rank r reads entry r+1;
+      * filtered history: the recursion is serial in z by definition, so the tails travel down the ranks one after the
+        other: step r = broadcast(src = r) of rank r's last m filtered slices; rank r+1 uses it, the others discard it.
+        world-1 broadcasts of m slices, each behind the sender's median kernel (~0.2 ms per link at 1024^2 x 128)."""
     median = median or _hip.median_harden_stack
     rank, world = _world(group)
     m = (int(ks) - 1) // 2
@@ -256,18 +265,22 @@ def median_handover(prob_local, ks, thr, group=None, median=None):
         return median(prob_local, ks, thr)
     D = prob_local.shape[0]
     assert D >= m, f"a block of {D} slices is shorter than the median's reach ({m})"
-    dev, tail = prob_local.device, tuple(prob_local.shape[1:])
-    # raw halo: my first m slices go left, the right neighbour's come in (independent of the recursion)
-    if rank > 0:
-        _send(prob_local[:m], rank - 1, group)
-    right = _recv((m,) + tail, prob_local.dtype, dev, rank + 1, group) if rank + 1 < world else None
-    left = _recv((m,) + tail, prob_local.dtype, dev, rank - 1, group) if rank > 0 else None
+    heads = _all_gather_cat(prob_local[:m].contiguous(), group)            # (world * m, C, H, W)
+    right = heads[(rank + 1) * m:(rank + 2) * m] if rank + 1 < world else None
+    tail = torch.empty_like(prob_local[:m])
+    left = None
+    for src in range(rank):                                                # tails of the ranks before this one
+        _broadcast(tail, src, group)
+        if src == rank - 1:
+            left = tail.clone()
     parts = [p for p in (left, prob_local, right) if p is not None]
-    ext = torch.cat(parts, dim=0)
-    sem, filt = median(ext, ks, thr, want_prob=True)
+    sem, filt = median(torch.cat(parts, dim=0), ks, thr, want_prob=True)
     lo = m if rank > 0 else 0
     if rank + 1 < world:
-        _send(filt[lo + D - m:lo + D], rank + 1, group)
+        tail.copy_(filt[lo + D - m:lo + D])
+        _broadcast(tail, rank, group)
+        for src in range(rank + 1, world - 1):                             # the ranks after this one hand over too
+            _broadcast(tail, src, group)
     return sem[lo:lo + D].contiguous()
 
 

@@ -101,8 +101,9 @@ def _worker(rank, world, port, bounds, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('split', [(7, 7), (5, 9)])
-def test_two_rank_chain_equals_single_rank(split):
+@pytest.mark.parametrize('split', [(7, 7), (5, 9), (2, 2, 2, 2, 1, 2, 1, 2)])
+def test_sharded_chain_equals_single_rank(split):
+    """world 2 and world 8 (the node's size, unequal blocks down to a single slice per rank)"""
     pan = make_stack()
     host, maps = cpu_tables(pan, [1, 2], [1])
     final, _ = chain_from_tables(host, pan.shape[0], [1, 2], [1], DIV, 0.25, 0.25)
@@ -115,14 +116,15 @@ def test_two_rank_chain_equals_single_rank(split):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bounds, q)) for r in range(2)]
+    world = len(split)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bounds, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=120) for _ in range(2))
+    got = dict(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    np.testing.assert_array_equal(np.concatenate([got[0], got[1]]), expected)
+    np.testing.assert_array_equal(np.concatenate([got[r] for r in range(world)]), expected)
 
 
 def test_shard_bounds():
@@ -255,7 +257,7 @@ def _worker_median(rank, world, port, bounds, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('split', [(7, 7), (3, 11), (4, 5, 5), (3, 3, 3, 5)])
+@pytest.mark.parametrize('split', [(7, 7), (3, 11), (4, 5, 5), (3, 3, 3, 5), (3, 5, 4, 3, 6, 3, 4, 4)])
 def test_median_handover_equals_whole_axis(split):
     """the rank-to-rank hand-over of filtered history + raw halo reproduces the recursive whole-axis median bit for
     bit, for equal and unequal blocks down to the minimum block size (ks // 2 slices)"""
