@@ -9,10 +9,19 @@ checkpoint `{'state_dict', 'norms', 'run_id'}` with the `module.` prefix strippe
 
 A TorchScript archive runs through the TorchScript interpreter with library kernels only.  To run it on this
 repository's kernels the archive is used for what it is on this path -- a container of named tensors: its state dict
-is read (state-dict keys of the exported classes equal the training classes', and both equal this package's), the
-architecture is inferred from the archive's class name and tensor shapes (the descriptor does not name the encoder),
-this package's module of the same architecture is built, loaded with `strict=True`, and handed to
-`prepare_for_inference`.
+is read, the architecture is inferred from the archive's class name and the shapes of its convolution weights (the
+descriptor does not name the encoder), this package's module of the same architecture is built, loaded with
+`strict=True`, and handed to `prepare_for_inference`.
+
+Two key layouts occur.  A training checkpoint (and an archive scripted without fusing) has the training classes' keys,
+which equal this package's.  scripts/export_model.py:115-120 calls `model.fuse_model()` before `torch.jit.script`:
+`torch.quantization.fuse_modules` folds every eval-mode BatchNorm of the encoder, the ASPP / first projection of the
+decoders and the PointRend MLP into the preceding convolution (folded weight + a new conv bias; the BatchNorm becomes
+an Identity and its tensors disappear) and wraps conv + ReLU pairs in a `ConvReLU2d`, which moves the convolution's
+keys one level down (`encoder.conv1.weight` -> `encoder.conv1.0.weight`).  `unfuse_state_dict` maps such a state dict
+back onto this package's modules: the wrapper level is stripped, and a BatchNorm whose tensors are gone is loaded as
+the identity plus the folded bias (weight 1, bias = the convolution's folded bias, running_mean 0, running_var 1 and
+eps 1e-30 -- torch insists on eps > 0, and 1 + 1e-30 == 1 -- so that it computes x + bias exactly).
 """
 import os
 
@@ -21,7 +30,7 @@ import torch
 from . import panoptic_bifpn as BF
 from . import panoptic_deeplab as DL
 
-__all__ = ['load_exported', 'load_checkpoint', 'infer_architecture', 'model_from_state_dict']
+__all__ = ['load_exported', 'load_checkpoint', 'infer_architecture', 'model_from_state_dict', 'unfuse_state_dict']
 
 _CLASSES = {'PanopticDeepLab': DL.PanopticDeepLab, 'PanopticDeepLabPR': DL.PanopticDeepLabPR,
             'PanopticBiFPN': BF.PanopticBiFPN, 'PanopticBiFPNPR': BF.PanopticBiFPNPR}
@@ -31,10 +40,85 @@ def _shapes(sd):
     return {k: tuple(v.shape) for k, v in sd.items()}
 
 
+def _conv_key(want, key):
+    """name under which the weight / bias `key` of one of this package's convolutions is stored in `want`: the key
+    itself, or one level down inside the ConvReLU wrapper fuse_modules puts around a conv + ReLU pair"""
+    if key in want:
+        return key
+    stem, leaf = key.rsplit('.', 1)
+    wrapped = f'{stem}.0.{leaf}'
+    return wrapped if wrapped in want else None
+
+
+def _conv_weights(shapes):
+    return {k: v for k, v in shapes.items() if k.endswith('.weight') and len(v) >= 3}
+
+
+def _bn_partners(model):
+    """{BatchNorm module name: name of the convolution it normalises} from the module tree: the convolution is the
+    BatchNorm's previous sibling (conv1, bn1, conv2, bn2, ... of a bottleneck; (conv, bn[, relu]) of a Sequential) or,
+    if that sibling is a block, the last convolution inside it"""
+    convs = (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.ConvTranspose2d)
+    out = {}
+    for pname, parent in model.named_modules():
+        prev = None
+        for cname, child in parent.named_children():
+            full = f'{pname}.{cname}' if pname else cname
+            if isinstance(child, torch.nn.modules.batchnorm._BatchNorm) and prev is not None:
+                out[full] = prev
+            if isinstance(child, convs):
+                prev = full
+            else:
+                inner = [n for n, m in child.named_modules() if isinstance(m, convs)]
+                if inner:
+                    prev = f'{full}.{inner[-1]}'
+    return out
+
+
+def unfuse_state_dict(model, state_dict):
+    """`state_dict` in either layout (module docstring) -> (state dict with exactly `model`'s keys, names of the
+    BatchNorm modules that were folded away and must compute x + bias: the caller makes their eps vanish)."""
+    own = model.state_dict()
+    partners = _bn_partners(model)
+    out, folded, used = {}, [], set()
+    for key, ref in own.items():
+        stem, leaf = key.rsplit('.', 1)
+        src = _conv_key(state_dict, key)
+        if src is not None:
+            out[key] = state_dict[src]
+            used.add(src)
+            continue
+        if stem in partners:                                     # a BatchNorm that fuse_modules folded away
+            bias = _conv_key(state_dict, partners[stem] + '.bias')
+            if bias is None:
+                raise KeyError(f'{key}: neither the BatchNorm tensor nor a folded bias of {partners[stem]} is in the archive')
+            used.add(bias)
+            if stem not in folded:
+                folded.append(stem)
+            b = state_dict[bias]
+            out[key] = {'weight': torch.ones_like(b), 'bias': b, 'running_mean': torch.zeros_like(b),
+                        'running_var': torch.ones_like(b),
+                        'num_batches_tracked': torch.zeros((), dtype=torch.long)}[leaf].to(ref.dtype)
+            continue
+        raise KeyError(f'{key} is not in the archive (fused or not)')
+    extra = sorted(set(state_dict) - used)
+    if extra:
+        raise KeyError(f'archive tensors without a place in {type(model).__name__}: {extra[:5]}{" ..." if len(extra) > 5 else ""}')
+    return out, folded
+
+
 def infer_architecture(state_dict, class_name=None):
-    """(arch name, constructor kwargs) whose module has exactly the keys and shapes of `state_dict`.
+    """(arch name, constructor kwargs) whose module has exactly the convolutions (names up to the ConvReLU wrapper
+    level, shapes) of `state_dict`.  Convolution weights only: BatchNorm tensors are absent from a fused export.
     class_name: the archive's class (`original_name`, with or without the `Quantizable` prefix), if known."""
     want = _shapes(state_dict)
+
+    def shape(key):
+        k = _conv_key(want, key)
+        if k is None:
+            raise KeyError(key)
+        return want[k]
+
     has_pr = any(k.startswith('semantic_pr.') for k in want)
     is_bifpn = any(k.startswith('semantic_fpn.') for k in want)
     arch = ('PanopticBiFPN' if is_bifpn else 'PanopticDeepLab') + ('PR' if has_pr else '')
@@ -42,20 +126,21 @@ def infer_architecture(state_dict, class_name=None):
         named = class_name.replace('Quantizable', '')
         if named in _CLASSES and named != arch:
             raise ValueError(f"archive class {class_name} does not match its tensors (look like {arch})")
-    num_classes = want['semantic_head.head.1.weight'][0]
+    num_classes = shape('semantic_head.head.1.weight')[0]
     base = dict(num_classes=num_classes, ins_decoder=any(k.startswith(('instance_decoder.', 'instance_fpn.')) for k in want))
     if is_bifpn:
-        base['fpn_dim'] = want['semantic_head.head.1.weight'][1]
+        base['fpn_dim'] = shape('semantic_head.head.1.weight')[1]
         base['fpn_layers'] = 1 + max(int(k.split('.')[2]) for k in want if k.startswith('semantic_fpn.bifpns.')) \
             if any(k.startswith('semantic_fpn.bifpns.') for k in want) else 3
         encoders = list(BF.REGNETS) + list(DL._RESNETS)
     else:
-        base['decoder_channels'] = want['semantic_head.head.1.weight'][1]
-        base['aspp_channels'] = want['semantic_decoder.aspp.project.0.weight'][0]
-        proj = sorted(int(k.split('.')[2]) for k in want if k.startswith('semantic_decoder.project.') and k.endswith('.0.weight'))
-        base['low_level_channels_project'] = tuple(want[f'semantic_decoder.project.{i}.0.weight'][0] for i in proj)
+        base['decoder_channels'] = shape('semantic_head.head.1.weight')[1]
+        base['aspp_channels'] = shape('semantic_decoder.aspp.project.0.weight')[0]
+        proj = sorted({int(k.split('.')[2]) for k in want if k.startswith('semantic_decoder.project.')})
+        base['low_level_channels_project'] = tuple(shape(f'semantic_decoder.project.{i}.0.weight')[0] for i in proj)
         base['low_level_stages'] = tuple(range(len(proj), 0, -1))
         encoders = list(DL._RESNETS)
+    n_convs = len(_conv_weights(want))
     errors = []
     for enc in encoders:
         kw = dict(base, encoder=enc)
@@ -65,9 +150,12 @@ def infer_architecture(state_dict, class_name=None):
         except Exception as e:                     # a candidate the constructor rejects is simply not the one
             errors.append(f'{enc}: {e}')
             continue
-        if _shapes(cand.state_dict()) == want:
+        convs = _conv_weights(_shapes(cand.state_dict()))
+        # aliased parameters (PanopticBiFPN's shared after_combines) are listed once per alias on both sides
+        if len(convs) == n_convs and all(_conv_key(want, k) is not None and want[_conv_key(want, k)] == v
+                                         for k, v in convs.items()):
             return arch, kw
-    raise ValueError(f"no {arch} configuration of this package has the archive's {len(want)} tensors "
+    raise ValueError(f"no {arch} configuration of this package has the archive's {n_convs} convolutions "
                      f"(tried encoders {encoders}); pass the constructor arguments explicitly")
 
 
@@ -80,7 +168,11 @@ def model_from_state_dict(state_dict, class_name=None, arch=None, **model_kwargs
     else:
         kw = dict(model_kwargs)
     model = _CLASSES[arch](**kw)
+    sd, folded = unfuse_state_dict(model, sd)
     model.load_state_dict(sd, strict=True)
+    mods = dict(model.named_modules())
+    for name in folded:
+        mods[name].eps = 1e-30                      # weight 1, mean 0, var 1 (+ 1e-30 == 1): exactly x + folded bias
     return model.eval(), arch, kw
 
 

@@ -70,10 +70,13 @@ def test_training_checkpoint(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/empanada'), reason='reference not present (GPU box)')
-def test_archive_scripted_from_the_reference_class(tmp_path):
-    """build container only: the archive scripts/export_model.py would write -- the REFERENCE's
-    QuantizablePanopticDeepLabPR, scripted and saved in a scratch directory (never committed) -- loads into this
-    package's PanopticDeepLabPR and both give the same heads through the exported 3-argument forward."""
+@pytest.mark.parametrize('layout', ['fused', 'plain'])
+def test_archive_scripted_from_the_reference_class(tmp_path, layout):
+    """build container only: the archive scripts/export_model.py writes -- the REFERENCE's
+    QuantizablePanopticDeepLabPR, `fuse_model()` applied as the script does (layout 'fused': ConvReLU2d wrappers,
+    BatchNorms folded into conv biases, 187 tensors instead of 423) or not ('plain'), scripted and saved in a scratch
+    directory (never committed) -- loads into this package's PanopticDeepLabPR and both give the same heads through
+    the exported 3-argument forward."""
     import subprocess
     code = r'''
 import sys
@@ -86,6 +89,8 @@ import torch
 from empanada.models.quantization import panoptic_deeplab as Q
 from empanada_amd.models import synthesize_weights
 m = synthesize_weights(Q.QuantizablePanopticDeepLabPR(encoder='resnet50', num_classes=1, quantize=False)).eval()
+if sys.argv[3] == 'fused':
+    m.fuse_model()                      # scripts/export_model.py:115-120: eval, fuse, then script
 torch.jit.save(torch.jit.script(m), sys.argv[1])
 x = torch.randn(1, 1, 96, 96, generator=torch.Generator().manual_seed(0))
 with torch.no_grad():
@@ -93,7 +98,7 @@ with torch.no_grad():
 torch.save({k: v for k, v in out.items()}, sys.argv[2])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     arch_path, out_path = str(tmp_path / 'PanopticDeepLabPR_ref.pth'), str(tmp_path / 'out.pt')
-    r = subprocess.run([sys.executable, '-c', code, arch_path, out_path], capture_output=True, text=True, cwd='/tmp')
+    r = subprocess.run([sys.executable, '-c', code, arch_path, out_path, layout], capture_output=True, text=True, cwd='/tmp')
     assert r.returncode == 0, r.stderr[-3000:]
     model, desc = EX.load_exported(_descriptor(tmp_path, arch_path), device='cpu', prepare=False)
     assert desc['arch'] == 'PanopticDeepLabPR' and desc['model_kwargs']['encoder'] == 'resnet50'
