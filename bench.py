@@ -79,10 +79,18 @@ MFMA_KERNELS = ('emp_conv_bn_act_nhwc', 'emp_conv_bn_act_proj_nhwc', 'emp_gemm_n
 MFMA_F32_PEAK_TFLOPS = 157.3                   # dense fp32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FLOPS_PER_VOXEL_PDL_R50 = 414477.0             # PanopticDeepLab-R50, C = 1, per input pixel
+FLOPS_PER_VOXEL = {'pdl_r50': 414477.0, 'mitonet_pr': 560798.0}     # SURVEY 8(d); the others were not counted
+COARSE = False                                 # mitonet_pr: instance heads at 1/4 resolution (engines.py:248-275, step 4)
+MITO = dict(encoder='resnet50', num_classes=1, stage4_stride=16, decoder_channels=256, low_level_stages=[1],
+            low_level_channels_project=[32], atrous_rates=[2, 4, 6], aspp_channels=None, aspp_dropout=0.5,
+            ins_decoder=True, ins_ratio=0.5)    # projects/mitonet/configs/mmm_panoptic_deeplab_pointrend.yaml:8-28
 
 # --model name -> label in config.workload (the FLOP count above is only known for the headline model)
 MODELS = {'pdl_r50': 'PanopticDeepLab/ResNet-50', 'bifpn_r50': 'PanopticBiFPN/ResNet-50',
-          'bifpn_regnety': 'PanopticBiFPN/RegNetY-6.4GF'}
+          'bifpn_regnety': 'PanopticBiFPN/RegNetY-6.4GF',
+          'mitonet_pr': 'PanopticDeepLabPR/ResNet-50 = the MitoNet configuration (instance decoder, PointRend semantic '
+                        'head with 2 render steps, 1/4-resolution instance heads -> step-4 grouping)'}
+MODEL_ARGS = {'mitonet_pr': (2, False)}        # forward(x, render_steps, interpolate_ins): engines.py:248-256
 
 
 def parse():
@@ -152,10 +160,12 @@ _T0 = time.perf_counter()
 
 # ----------------------------------------------------------------------------------------------- model
 def build_model(name):
-    from empanada_amd.models import PanopticBiFPN, PanopticDeepLab, synthesize_weights
+    from empanada_amd.models import PanopticBiFPN, PanopticDeepLab, PanopticDeepLabPR, synthesize_weights
     nc = 1 if len(LABELS) == 1 else len(LABELS) + 1              # binary head, or background + T classes
     if name == 'pdl_r50':
         model = PanopticDeepLab(encoder='resnet50', num_classes=nc)
+    elif name == 'mitonet_pr':
+        model = PanopticDeepLabPR(**dict(MITO, num_classes=nc))
     else:
         model = PanopticBiFPN(encoder={'bifpn_r50': 'resnet50', 'bifpn_regnety': 'regnety_6p4gf'}[name], num_classes=nc)
     model = synthesize_weights(model)
@@ -170,6 +180,7 @@ class Pipeline:
         from empanada_amd.models import prepare_for_inference
         self.dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[args.dtype]
         self.model = prepare_for_inference(build_model(args.model), device, self.dtype)
+        self.model_args = MODEL_ARGS.get(args.model, ())
         self.device = device
         self.batch = args.batch
         self.tune_batch = args.tune_batch
@@ -212,7 +223,7 @@ class Pipeline:
         # and MIOpen's exhaustive find on the full-size shapes of all 66 sites would take minutes of warm-up
         n = max(1, min(self.slices_per_call(size, size), self.tune_batch * 512 * 512 // (size * size)))
         x = torch.rand((n, 1, size, size), device=self.device).contiguous(memory_format=torch.channels_last)
-        rep = tune_fused_convs(self.model, x, allow=self.conv_impls)
+        rep = tune_fused_convs(self.model, x, allow=self.conv_impls, model_args=self.model_args)
         for _, (best, _) in rep.items():
             counts[best] = counts.get(best, 0) + 1
         self.tuned = counts
@@ -263,11 +274,11 @@ class Pipeline:
         hp, wp = dv.padded_shape(axis)
         for s in range(lo, hi, per):
             e = min(hi, s + per)
-            buf = model.input_buffer((e - s, 1, hp, wp)) if model is self.graphed else None
+            buf = model.input_buffer((e - s, 1, hp, wp), args=self.model_args) if model is self.graphed else None
             x = dv.batch(axis, s, e, out=buf)        # straight into the graph's input: no device-to-device copy
             if self.dtype != torch.float32:
                 x = x.to(self.dtype)
-            out = model(x.contiguous(memory_format=torch.channels_last))
+            out = model(x.contiguous(memory_format=torch.channels_last), *self.model_args)
             logits = out['sem_logits'][..., :h, :w].float()          # logits_to_prob, engines.py:22-30
             dst = prob[s - lo:s - lo + x.shape[0]]                   # written in place: no temporary + device copy
             if self.dtype == torch.float32:
@@ -285,7 +296,7 @@ class Pipeline:
         (empanada_amd/inference/sharded.py); with one rank the collectives are no-ops."""
         from empanada_amd.inference import sharded
         pan = sharded.sharded_panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'],
-                                             coarse_boundaries=False, **ENGINE)
+                                             coarse_boundaries=COARSE, **ENGINE)
         vol = sharded.sharded_stack_volume(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'],
                                            min_size=FILTERS['min_size'], min_span=FILTERS['min_span'], **MATCH)
         out_host.copy_(vol.view(torch.int32), non_blocking=True)
@@ -303,8 +314,8 @@ def forward_check(args, pipe, dv, axes=('xy', 'yz')):
     for axis in axes:
         z = dv.n_slices(axis) // 2
         x = dv.batch(axis, z, z + 1)
-        got = pipe.model(x.contiguous(memory_format=torch.channels_last))
-        ref = cpu_model(x.cpu())
+        got = pipe.model(x.contiguous(memory_format=torch.channels_last), *pipe.model_args)
+        ref = cpu_model(x.cpu(), *pipe.model_args)
         for k in ('sem_logits', 'ctr_hmp', 'offsets'):
             r = ref[k].float()
             g = got[k].float().cpu()
@@ -329,7 +340,7 @@ def build_inputs(D, S, device, seed_offset=0, things=1):
     heads = {'sem': [], 'ctr_hmp': [], 'offsets': []}
     for s in range(0, D, 64):                    # chunked to bound the generator's temporaries
         h = SY.planted_heads(lab_dev, cls, 'xy', device=device, slices=slice(s, min(D, s + 64)), seed=99 + s,
-                             n_classes=things)
+                             n_classes=things, coarse=COARSE)
         for k in heads:
             heads[k].append(h[k])
     heads = {k: torch.cat(v, dim=0).contiguous() for k, v in heads.items()}
@@ -391,7 +402,7 @@ def build_inputs_ortho(S, device, rank=0, world=1, labels_out=None, things=1):
         parts = {'sem': [], 'ctr_hmp': [], 'offsets': []}
         for s in range(lo, hi, chunk):
             h = SY.planted_heads(lab_dev, cls, axis, device=device, slices=slice(s, min(hi, s + chunk)), seed=99 + s,
-                                 n_classes=things)
+                                 n_classes=things, coarse=COARSE)
             for k in parts:
                 parts[k].append(h[k])
         heads[axis] = {k: torch.cat(v, dim=0).contiguous() for k, v in parts.items()}
@@ -415,7 +426,7 @@ def postprocess_planes(heads, shape3d, writer, stages, between=None, before=None
         if before is not None:
             before(axis)
         h = heads[axis]
-        pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=False, **ENGINE)
+        pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=COARSE, **ENGINE)
         table, host = sharded.sharded_tables(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'])
         t1 = time.perf_counter()
         if between is not None:
@@ -510,7 +521,7 @@ def cpu_baseline_ortho(args, n, cores):
     em = SY.em_volume(shape, seed=1234)
     T = len(LABELS)
     lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321, n_classes=T)
-    heads = {a: SY.planted_heads(lab, cls, a, seed=99, n_classes=T) for a in ('xy', 'xz', 'yz')}
+    heads = {a: SY.planted_heads(lab, cls, a, seed=99, n_classes=T, coarse=COARSE) for a in ('xy', 'xz', 'yz')}
     model = build_model(args.model).eval()
     t0 = time.perf_counter()
     for ax, axis in enumerate(('xy', 'xz', 'yz')):
@@ -518,14 +529,14 @@ def cpu_baseline_ortho(args, n, cores):
         x = (x - 255 * NORM['mean']) / (255 * NORM['std'])
         with torch.no_grad():
             for i in range(n):
-                out = model(x[i:i + 1])
+                out = model(x[i:i + 1], *MODEL_ARGS.get(args.model, ()))
                 _ = torch.sigmoid(out['sem_logits']) if T == 1 else torch.softmax(out['sem_logits'], dim=1)
     t_conv = time.perf_counter() - t0
     # oracle/pipeline.py: the per-pixel stages on `cores` processes, matching / tracking / consensus serial as in the
     # reference (one matcher process, scripts/pdl_inference3d.py:143-151)
     np_heads = {a: {k: v.numpy() for k, v in heads[a].items()} for a in heads}
-    refs, n_inst, _ = PL.orthoplane_volume(np_heads, shape, ENGINE, MATCH, FILTERS, CONSENSUS, labels=LABELS,
-                                           workers=cores)
+    refs, n_inst, _ = PL.orthoplane_volume(np_heads, shape, dict(ENGINE, coarse_boundaries=COARSE), MATCH, FILTERS,
+                                           CONSENSUS, labels=LABELS, workers=cores)
     dt = time.perf_counter() - t0
     # the HIP path on exactly the same heads
     dev_heads = {a: {k: v.cuda().contiguous() for k, v in heads[a].items()} for a in heads}
@@ -635,7 +646,7 @@ def main_orthoplane(args, device, rank, world):
                                f'(BASELINE configs[{3 if S >= 1024 else 2}] volume), {MODELS[args.model]} '
                                f'C={1 if len(LABELS) == 1 else len(LABELS) + 1} fp32 '
                                f'forward on every slice of every plane + HIP post-processing on planted heads '
-                               f'(ks=7, full-res heads), {n_obj} planted objects, slices of every plane sharded over '
+                               f'(ks=7, {"1/4-res instance" if COARSE else "full-res"} heads), {n_obj} planted objects, slices of every plane sharded over '
                                f'{world} rank(s); labelled uint32 volume copied to the host and written as a zarr v2 '
                                f'array (chunks (1,Y,X), uncompressed) under {os.path.dirname(out_dir)}'
                                + (' (tmpfs: the write costs memory bandwidth, not disk)' if out_dir.startswith('/dev/shm')
@@ -644,9 +655,9 @@ def main_orthoplane(args, device, rank, world):
                    'batch': pipe.slices_per_call(S, S)},
         'breakdown': {'stages_s_per_step': {k: round(v / args.steps, 4) for k, v in stages.items()},
                       'hand_written_dense_ms_per_pass_rank0': round(fwd_ms_pass, 1),
-                      'forward_TFLOPs_if_gpu_bound': round(3 * FLOPS_PER_VOXEL_PDL_R50 * float(S) ** 3 / world
+                      'forward_TFLOPs_if_gpu_bound': round(3 * FLOPS_PER_VOXEL[args.model] * float(S) ** 3 / world
                                                            / (dt / args.steps) / 1e12, 2)
-                      if args.model == 'pdl_r50' and len(LABELS) == 1 else None,
+                      if args.model in FLOPS_PER_VOXEL and len(LABELS) == 1 else None,
                       'pipelined': not args.no_pipeline, 'conv_impls': pipe.tuned},
         'forward_checksum': chks[-1], 'forward_checksum_stable': bool(all(c == chks[0] for c in chks)),
         'hip_calls_ms': per_call, 'hip_ms_per_pass': per_pass, 'roofline': roof,
@@ -728,11 +739,11 @@ def cpu_baseline_stack(args, vol_u8, heads, n_slices):
     t0 = time.perf_counter()
     with torch.no_grad():
         for i in range(n):
-            out = model(x[i:i + 1])
+            out = model(x[i:i + 1], *MODEL_ARGS.get(args.model, ()))
             _ = torch.sigmoid(out['sem_logits']) if len(LABELS) == 1 else torch.softmax(out['sem_logits'], dim=1)
     t_conv = time.perf_counter() - t0
     pans = OP.engine3d_stack([sem[t:t + 1] for t in range(n)], [ctr[t:t + 1] for t in range(n)],
-                             [off[t:t + 1] for t in range(n)], coarse_boundaries=False, render=True, **ENGINE)
+                             [off[t:t + 1] for t in range(n)], coarse_boundaries=COARSE, render=True, **ENGINE)
     pans = [p.squeeze() for p in pans]
     matchers = OS.create_matchers(ENGINE['thing_list'], ENGINE['label_divisor'], MATCH['merge_iou_thr'],
                                   MATCH['merge_ioa_thr'])
@@ -754,7 +765,7 @@ def cpu_baseline_stack(args, vol_u8, heads, n_slices):
     from empanada_amd.evaluation import volume_pq
     from empanada_amd.inference import sharded
     sub = {k: heads[k][:n].contiguous() for k in heads}
-    pan = sharded.sharded_panoptic_stack(sub['sem'], sub['ctr_hmp'], sub['offsets'], coarse_boundaries=False, **ENGINE)
+    pan = sharded.sharded_panoptic_stack(sub['sem'], sub['ctr_hmp'], sub['offsets'], coarse_boundaries=COARSE, **ENGINE)
     got = sharded.sharded_stack_volume(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'],
                                        min_size=FILTERS['min_size'], min_span=FILTERS['min_span'], **MATCH)
     got = got.view(torch.int32).cpu().numpy().astype(np.uint32)
@@ -818,7 +829,7 @@ def main_stack(args, device, rank, world):
             with torch.cuda.stream(post):
                 post.wait_event(fwd_done[k])
                 pan = sharded.sharded_panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'],
-                                                     coarse_boundaries=False, **ENGINE)
+                                                     coarse_boundaries=COARSE, **ENGINE)
                 table, host = sharded.sharded_tables(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'])
                 tc = time.perf_counter()
                 final = sharded.gather_tables_and_chain(host, pan.shape[0], LABELS, ENGINE['thing_list'],
@@ -861,7 +872,7 @@ def main_stack(args, device, rank, world):
         thing_frac = float((heads['sem'].argmax(dim=1) > 0).float().mean().item())
     roof, per_call, per_pass = roofline_block(prof, float(D) * S * S, thing_frac, args.steps,
                                               dense_passes=1 if not args.no_pipeline else args.steps)
-    flops = FLOPS_PER_VOXEL_PDL_R50 * D * S * S
+    flops = FLOPS_PER_VOXEL.get(args.model, 0.0) * D * S * S
     res = {
         'metric': 'Mvox/s end-to-end 3D panoptic inference, xy stack only (no consensus); PQ vs CPU ref',
         'value': round(vox_total / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': world, 'steps': args.steps,
@@ -871,12 +882,12 @@ def main_stack(args, device, rank, world):
         'config': {'workload': f'stack (xy) inference, {D * world}x{S}x{S} uint8 volume (an independent {D}-slice '
                                f'volume per rank), {MODELS[args.model]} '
                                f'C={1 if len(LABELS) == 1 else len(LABELS) + 1} fp-forward on every slice + HIP '
-                               f'post-processing on planted heads (ks=7, full-res heads), {n_obj} planted objects per rank',
+                               f'post-processing on planted heads (ks=7, {"1/4-res instance" if COARSE else "full-res"} heads), {n_obj} planted objects per rank',
                    'mode': 'stack', 'slices_per_rank': D, 'batch': pipe.slices_per_call(S, S),
                    'objects_found': int(len(np.unique(host_out.numpy())) - 1)},
         'breakdown_ms': {'forward': round(float(fwd_ms), 2), 'forward_end_to_slab_on_host': round(float(post_ms), 2),
                          'forward_TFLOPs': round(flops / (fwd_ms * 1e-3) / 1e12, 2)
-                         if args.model == 'pdl_r50' and len(LABELS) == 1 else None,
+                         if args.model in FLOPS_PER_VOXEL and len(LABELS) == 1 else None,
                          'pipelined': not args.no_pipeline, 'conv_impls': pipe.tuned,
                          'host_chain_s': round(float(np.mean(pipe.timers.get('chain_s', [0]))), 4)},
         'forward_checksum': chks[-1], 'forward_checksum_stable': bool(all(c == chks[0] for c in chks)),
@@ -895,6 +906,9 @@ def main_stack(args, device, rank, world):
 def main():
     args = parse()
     maybe_spawn(args)
+    if float(os.environ.get('EMP_BENCH_WATCHDOG', 0)) > 0:      # stack traces of every thread, every N seconds: where a
+        import faulthandler                                      # rank sits if a multi-rank run ever stops moving
+        faulthandler.dump_traceback_later(float(os.environ['EMP_BENCH_WATCHDOG']), repeat=True, file=sys.stderr)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -915,9 +929,13 @@ def main():
     if args.things > 1:
         LABELS[:] = list(range(1, args.things + 1))
         ENGINE['thing_list'] = list(LABELS)
+    global COARSE
+    COARSE = args.model == 'mitonet_pr'
     (main_orthoplane if args.mode == 'orthoplane' else main_stack)(args, device, rank, world)
     if world > 1:
+        log(f'rank {rank}: leaving the process group')
         dist.destroy_process_group()
+    log(f'rank {rank}: done')
 
 
 if __name__ == '__main__':

@@ -92,6 +92,7 @@ SIGNATURES = {
     'emp_track_work_elems': (_L, [_L]),
     'emp_track_lift': (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, _P]),
     'emp_track_lift_yz': (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _I, _L, _P, _P, _P]),
+    'emp_tile_lift': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _L, _P, _P, _P, _P, _P]),
     'emp_track_sort_work_bytes': (_L, [_L]),
     'emp_track_sort': (_I, [_P, _P, _L, _I, _P, _L, _P, _P, _P, _P, _P]),
     'emp_track_offsets': (_I, [_P, _L, _L, _P, _P]),
@@ -155,11 +156,19 @@ def stream():
 # pass in one pass only, so that event packets do not perturb the others).
 PROFILE = None
 PROFILE_SKIP = set()
+# EMP_TRACE_CALLS=<file>: append one line per ABI call (name + integer arguments) BEFORE it is enqueued, flushed at
+# once -- the tail of the file names the launches that were in flight when a queue aborts (tools/pmc_abort_probe.sh).
+_TRACE = None
+if os.environ.get('EMP_TRACE_CALLS'):
+    _TRACE = open(os.environ['EMP_TRACE_CALLS'], 'a', buffering=1)
 
 
 def call(name, *args, alg_bytes=None, alg_flops=None):
     """Call an int-returning ABI function; raise HipError with emp_last_error() on failure."""
     lib = load()
+    if _TRACE is not None:
+        _TRACE.write(name + ' ' + ' '.join(str(a) for a in args if isinstance(a, (int, float)) and abs(a) < (1 << 40))
+                     + '\n')
     if PROFILE is not None and name not in PROFILE_SKIP:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)

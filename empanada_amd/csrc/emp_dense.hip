@@ -475,9 +475,10 @@ extern "C" int emp_bn_relu_maxpool_nhwc(const float *x, const float *scale, cons
 // ------------------------------------------------------------------------------------------
 // D2: logits_to_prob (engines.py:22-30): sigmoid for one channel, softmax over the channel axis otherwise, planar
 // (N, C, HW) fp32.  One streaming pass; every lane owns 4 consecutive pixels (float4 per channel plane).
+// y may be x itself (in place): no __restrict__ here -- a lane reads every channel of its pixels in the first two
+// loops and, in the third, each channel again right before it stores that same address.
 template <int VEC>
-__global__ __launch_bounds__(256) void logits_to_prob_kernel(const float *__restrict__ x, int C, int64_t HW, int64_t total,
-                                                             float *__restrict__ y)
+__global__ __launch_bounds__(256) void logits_to_prob_kernel(const float *x, int C, int64_t HW, int64_t total, float *y)
 {
     // total = N * HW / VEC work items; item i covers pixels [VEC * (i % (HW / VEC)), +VEC) of image i / (HW / VEC)
     const int64_t per = HW / VEC;

@@ -42,7 +42,7 @@ __global__ void trk_heads_kernel(const int32_t *__restrict__ r_start, const int3
 __global__ void trk_emit_kernel(int axis, const int32_t *__restrict__ r_start, const int32_t *__restrict__ r_len,
                                 const int32_t *__restrict__ r_comp, const int32_t *__restrict__ c_slice,
                                 const int32_t *__restrict__ comp_inst, int64_t n, int W, int64_t YX, int X,
-                                int slice0, int64_t inst_base, const int32_t *__restrict__ head,
+                                int slice0, int64_t inst_base, int64_t origin, const int32_t *__restrict__ head,
                                 const int32_t *__restrict__ pos, uint64_t *__restrict__ out_key,
                                 int64_t *__restrict__ out_len)
 {
@@ -56,8 +56,10 @@ __global__ void trk_emit_kernel(int axis, const int32_t *__restrict__ r_start, c
         int64_t sl = (int64_t)c_slice[comp] + slice0;
         int64_t st3;
         if (axis == 0) st3 = st + sl * YX;                                   // plane (Y, X), slices along z
-        else st3 = (st / W) * YX + sl * (int64_t)X + (st % W);               // plane (Z, X), slices along y: only the
+        else if (axis == 1) st3 = (st / W) * YX + sl * (int64_t)X + (st % W);   // plane (Z, X), slices along y: only the
                                                                              // START is mapped (tracker.py:78-82)
+        else st3 = (st / W) * (int64_t)X + (st % W) + origin;                // tile (., W) inside an image (., X): 2D
+                                                                             // start, length kept (tile.py:155-166)
         int64_t o = pos[i];
         out_key[o] = ((uint64_t)(inst_base + comp_inst[comp]) << TRK_POS_BITS) | (uint64_t)st3;
         out_len[o] = len;
@@ -94,10 +96,47 @@ extern "C" int emp_track_lift(int axis, const int32_t *r_start, const int32_t *r
     int rc = emp_exclusive_scan_i32(head, n_runs, pos, tmp, stream);
     if (rc != EMP_OK) return rc;
     hipLaunchKernelGGL(trk_emit_kernel, dim3(grid), dim3(256), 0, st, axis, r_start, r_len, r_comp, c_slice,
-                       comp_inst, n_runs, W, (int64_t)Y * X, X, slice0, inst_base, head, pos, out_key, out_len);
+                       comp_inst, n_runs, W, (int64_t)Y * X, X, slice0, inst_base, (int64_t)0, head, pos, out_key,
+                       out_len);
     EMP_CHECK_LAUNCH("emp_track_lift(emit)");
     if (hipMemcpyAsync(n_out, pos + n_runs, sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
         EMP_FAIL(EMP_ELAUNCH, "track_lift: count copy");
+    return EMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ tile lift (C5)
+// Tiler.translate_rle_seg (empanada/inference/tile.py:122-168) for a whole stack of one tile's slices: the runs of
+// every object (component of the tile's run table) merged where rle_encode of its flat TILE indices would merge them
+// (a run ending at the tile's last column continues at column 0 of the next row, array_utils.py:209-235), the START
+// mapped into the image frame -- (start / tw + y0) * X + start % tw + x0 -- and the length kept, so a run that wrapped
+// inside the tile runs on past the tile's right edge in the image, exactly as in the reference.  Positions are 2D
+// (the slice is carried by the object): key = (inst_base + comp_inst[comp]) << 40 | start2d.
+extern "C" int emp_tile_lift(const int32_t *r_start, const int32_t *r_len, const int32_t *r_comp,
+                             const int32_t *c_slice, const int32_t *comp_inst, int64_t n_runs, int tw, int X, int y0,
+                             int x0, int64_t inst_base, int32_t *work, uint64_t *out_key, int64_t *out_len,
+                             int32_t *n_out, void *stream)
+{
+    EMP_REQUIRE(n_runs >= 0 && n_runs < (1LL << 31) && tw > 0 && X >= tw && y0 >= 0 && x0 >= 0 && x0 + tw <= X && n_out,
+                "tile_lift: bad sizes");
+    hipStream_t st = emp_stream(stream);
+    if (n_runs == 0) {
+        if (hipMemsetAsync(n_out, 0, sizeof(int32_t), st) != hipSuccess) EMP_FAIL(EMP_ELAUNCH, "tile_lift: memset");
+        return EMP_OK;
+    }
+    EMP_REQUIRE(r_start && r_len && r_comp && c_slice && comp_inst && work && out_key && out_len,
+                "tile_lift: null pointer");
+    int32_t *head = work, *pos = work + n_runs, *tmp = work + 2 * n_runs + 2;
+    int grid = emp_grid(n_runs, 256, 4096);
+    hipLaunchKernelGGL(trk_heads_kernel, dim3(grid), dim3(256), 0, st, r_start, r_len, r_comp, c_slice, comp_inst,
+                       n_runs, head);
+    EMP_CHECK_LAUNCH("emp_tile_lift(heads)");
+    int rc = emp_exclusive_scan_i32(head, n_runs, pos, tmp, stream);
+    if (rc != EMP_OK) return rc;
+    hipLaunchKernelGGL(trk_emit_kernel, dim3(grid), dim3(256), 0, st, 2, r_start, r_len, r_comp, c_slice, comp_inst,
+                       n_runs, tw, (int64_t)0, X, 0, inst_base, (int64_t)y0 * X + x0, head, pos, out_key, out_len);
+    EMP_CHECK_LAUNCH("emp_tile_lift(emit)");
+    if (hipMemcpyAsync(n_out, pos + n_runs, sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        EMP_FAIL(EMP_ELAUNCH, "tile_lift: count copy");
     return EMP_OK;
 }
 

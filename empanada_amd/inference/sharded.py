@@ -384,12 +384,19 @@ def gather_plane_tracks(pt, group=None):
 
 
 def consensus_volume(planes, shape3d, labels, thing_list, pixel_vote_thr=2, cluster_iou_thr=0.75, bypass=False,
-                     min_size=None, min_span=None, group=None):
+                     min_size=None, min_span=None, group=None, on_degenerate='zero'):
     """Orthoplane mode, last step (scripts/pdl_inference3d.py:200-233): per-plane filters, instance / semantic
     consensus per class, filters again, fill -- sharded by z-slab of the OUTPUT volume.
 
     planes: {'xy': PlaneTracks, 'xz': ..., 'yz': ...} whose instance indices are disjoint (inst_base) and ascending in
     that order.  Every rank votes on and paints the flat voxel interval [z0 * Y * X, z1 * Y * X) of its own z-slab.
+
+    on_degenerate: the reference's merge functions crash on a degenerate class -- a stuff class voted empty (present in
+    fewer planes than pixel_vote_thr: IndexError, consensus.py:331-339) or pixel_vote_thr == 1 with a one-run object
+    (UnboundLocalError / ValueError out of join_ranges, array_utils.py:659-671).  `empanada_amd.consensus` keeps those
+    exceptions (bug parity of the reference API); this driver runs at the very END of a volume's work, so by default
+    ('zero') it warns and gives that class an all-zero volume instead of losing every class; 'raise' re-raises.  The
+    conditions are evaluated on all-reduced counts, so every rank takes the same branch.
     Returns ({class: ConsensusResult}, {class: (z1 - z0, Y, X) device slab, uint32 things / uint8 stuff}, (z0, z1))."""
     from .. import consensus as CO
     rank, world = _world(group)
@@ -434,18 +441,28 @@ def consensus_volume(planes, shape3d, labels, thing_list, pixel_vote_thr=2, clus
     cons, vols = {}, {}
     for class_id in labels:
         nodes = np.flatnonzero(alive & (cls == class_id))
-        if class_id in thing_list:
-            res = CO.consensus_objects(src[nodes], boxes[nodes], areas[nodes], store, len(order), pixel_vote_thr,
-                                       cluster_iou_thr, bypass, reduce=reduce, store_index=nodes)
-            if min_size is not None:
-                res.remove_small_objects(min_size)
-            if min_span is not None:
-                res.remove_pancakes(min_span)
-            vol = torch.zeros(((z1 - z0) * Y * X,), dtype=torch.int32, device=dev).view(torch.uint32)
-        else:
-            res = CO.consensus_semantic(src[nodes], boxes[nodes], store, pixel_vote_thr, reduce=reduce,
-                                        store_index=nodes)
-            vol = torch.zeros(((z1 - z0) * Y * X,), dtype=torch.uint8, device=dev)
+        thing = class_id in thing_list
+        try:
+            if thing:
+                res = CO.consensus_objects(src[nodes], boxes[nodes], areas[nodes], store, len(order), pixel_vote_thr,
+                                           cluster_iou_thr, bypass, reduce=reduce, store_index=nodes)
+                if min_size is not None:
+                    res.remove_small_objects(min_size)
+                if min_span is not None:
+                    res.remove_pancakes(min_span)
+            else:
+                res = CO.consensus_semantic(src[nodes], boxes[nodes], store, pixel_vote_thr, reduce=reduce,
+                                            store_index=nodes)
+        except (IndexError, UnboundLocalError, ValueError) as e:
+            if on_degenerate == 'raise':
+                raise
+            import warnings
+            warnings.warn(f"consensus of class {class_id} is degenerate ({type(e).__name__}: {e}; the reference crashes "
+                          f"here): the class is written as an all-zero volume", RuntimeWarning)
+            res = CO.ConsensusResult(np.zeros((0, 6)), np.zeros(0), None, np.zeros(1))
+        vol = torch.zeros(((z1 - z0) * Y * X,), dtype=torch.int32 if thing else torch.uint8, device=dev)
+        if thing:
+            vol = vol.view(torch.uint32)
         res.paint(vol, lo)
         cons[class_id] = res
         vols[class_id] = vol.reshape(z1 - z0, Y, X)

@@ -49,10 +49,10 @@ class GraphedForward(torch.nn.Module):
             static_out = self.model(static_in, *args, **kwargs)
         return graph, static_in, static_out
 
-    def input_buffer(self, shape, dtype=torch.float32, channels_last=True):
-        """the static input tensor of the graph captured for this input signature (no extra arguments), or None:
-        writing the next input straight into it saves the device-to-device copy in forward()"""
-        entry = self._graphs.get((tuple(shape), dtype, channels_last, (), ()))
+    def input_buffer(self, shape, dtype=torch.float32, channels_last=True, args=()):
+        """the static input tensor of the graph captured for this input signature (and these extra positional
+        arguments), or None: writing the next input straight into it saves the device-to-device copy in forward()"""
+        entry = self._graphs.get((tuple(shape), dtype, channels_last, tuple(args), ()))
         return None if entry is None else entry[1]
 
     @torch.no_grad()

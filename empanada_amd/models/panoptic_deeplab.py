@@ -717,13 +717,14 @@ def pair_conv_bn(model):
 
 
 @torch.no_grad()
-def tune_fused_convs(model, example, reps=5, verbose=False, allow=None):
+def tune_fused_convs(model, example, reps=5, verbose=False, allow=None, model_args=()):
     """Pick, per FusedConvBNAct call site, the fastest of its implementations on the shapes `example` produces
     (isolated timing with HIP events).  `allow`: optional collection restricting the candidates (e.g.
     ('miopen', 'direct') to keep every convolution in the direct form: the Winograd forms are fp32 too but round
     differently -- F(2x2) about 2x, F(3x3) / F(4x4) about 10x the direct form's rounding error).
+    model_args: extra positional arguments of the model's forward (PointRend models: render_steps, interpolate_ins).
     Returns {module name: (chosen, {impl: ms})}."""
-    model(example)                                   # records the shapes (and lets MIOpen pick its kernels)
+    model(example, *model_args)                      # records the shapes (and lets MIOpen pick its kernels)
     report = {}
     for name, m in model.named_modules():
         if not isinstance(m, FusedConvBNAct) or m._seen is None:

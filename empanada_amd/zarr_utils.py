@@ -74,38 +74,44 @@ def chunk_ranges(ranges, modulo, divisor):
 
 
 def zarr_fill_instances(array, instances, processes=4):
-    """zarr_utils.py:88-175.  `processes` is accepted for signature compatibility; chunks are painted by the GPU."""
+    """zarr_utils.py:88-175.  `processes` is accepted for signature compatibility.  As in the reference every
+    instance's runs are split at the z / y / x chunk borders ONCE, bucketed by the chunk their start falls into
+    (:131-160), and every chunk that received something is read, painted (instances in dict order) and written once."""
     d, h, w = array.shape
     dc, hc, wc = array.chunks
-    for z1 in range(0, d, dc):
-        for y1 in range(0, h, hc):
-            for x1 in range(0, w, wc):
-                z2, y2, x2 = min(d, z1 + dc), min(h, y1 + hc), min(w, x1 + wc)
-                sl = (slice(z1, z2), slice(y1, y2), slice(x1, x2))
-                seg = np.ascontiguousarray(array[sl])
-                cshape = seg.shape
-                sub = {}
-                for instance_id, attrs in instances.items():
-                    rng = rle_to_ranges(np.stack([attrs['starts'], attrs['runs']], axis=1))
-                    rng = np.array(chunk_ranges(rng, d * h * w, dc * h * w)).reshape(-1, 2)
-                    rng = np.array(chunk_ranges(rng, h * w, hc * w)).reshape(-1, 2)
-                    rng = np.array(chunk_ranges(rng, w, wc)).reshape(-1, 2)
-                    if len(rng) == 0:
-                        continue
-                    zs, ys, xs = np.unravel_index(rng[:, 0], array.shape)
-                    keep = (zs >= z1) & (zs < z2) & (ys >= y1) & (ys < y2) & (xs >= x1) & (xs < x2)
-                    if not keep.any():
-                        continue
-                    # like fill_zarr_mp (:71-84) the chunk-local start and END are unravelled separately; a run
-                    # that leaves its chunk and comes back (row wrap over a narrow last chunk) is therefore
-                    # painted exactly as the reference paints it
-                    ze, ye, xe = np.unravel_index(rng[keep, 1] - 1, array.shape)
-                    starts = np.ravel_multi_index((zs[keep] - z1, ys[keep] - y1, xs[keep] - x1), cshape)
-                    ends = np.ravel_multi_index((ze - z1, ye - y1, xe - x1), cshape, mode='wrap') + 1
-                    sub[instance_id] = {'starts': starts.astype(np.int64),
-                                        'runs': np.maximum(ends - starts, 0).astype(np.int64)}
-                if sub:
-                    array[sl] = numpy_fill_instances(seg, sub).reshape(cshape)
+    ch, cw = math.ceil(h / hc), math.ceil(w / wc)
+    per_chunk = {}                                   # chunk index -> [(instance id, ranges)] in dict order
+    for instance_id, attrs in instances.items():
+        rng = rle_to_ranges(np.stack([attrs['starts'], attrs['runs']], axis=1))
+        rng = np.array(chunk_ranges(rng, d * h * w, dc * h * w)).reshape(-1, 2)
+        rng = np.array(chunk_ranges(rng, h * w, hc * w)).reshape(-1, 2)
+        rng = np.array(chunk_ranges(rng, w, wc)).reshape(-1, 2)
+        if len(rng) == 0:
+            continue
+        cidx = ((rng[:, 0] % (d * h * w)) // (dc * h * w)) * ch * cw + ((rng[:, 0] % (h * w)) // (hc * w)) * cw \
+            + (rng[:, 0] % w) // wc
+        order = np.argsort(cidx, kind='stable')
+        rng, cidx = rng[order], cidx[order]
+        uniq, first = np.unique(cidx, return_index=True)
+        for c, part in zip(uniq.tolist(), np.split(rng, first[1:])):
+            per_chunk.setdefault(c, []).append((instance_id, part))
+    for c in sorted(per_chunk):
+        z1, y1, x1 = (c // (ch * cw)) * dc, ((c // cw) % ch) * hc, (c % cw) * wc
+        z2, y2, x2 = min(d, z1 + dc), min(h, y1 + hc), min(w, x1 + wc)
+        sl = (slice(z1, z2), slice(y1, y2), slice(x1, x2))
+        seg = np.ascontiguousarray(array[sl])
+        cshape = seg.shape
+        sub = {}
+        for instance_id, rng in per_chunk[c]:
+            # like fill_zarr_mp (:71-84) the chunk-local start and END are unravelled separately; a run that leaves
+            # its chunk and comes back (row wrap over a narrow last chunk) is therefore painted exactly as the
+            # reference paints it
+            zs, ys, xs = np.unravel_index(rng[:, 0], array.shape)
+            ze, ye, xe = np.unravel_index(rng[:, 1] - 1, array.shape)
+            starts = np.ravel_multi_index((zs - z1, ys - y1, xs - x1), cshape)
+            ends = np.ravel_multi_index((ze - z1, ye - y1, xe - x1), cshape, mode='wrap') + 1
+            sub[instance_id] = {'starts': starts.astype(np.int64), 'runs': np.maximum(ends - starts, 0).astype(np.int64)}
+        array[sl] = numpy_fill_instances(seg, sub).reshape(cshape)
 
 
 def zarr_put3d(stack, index, value, axis):

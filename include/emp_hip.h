@@ -487,6 +487,13 @@ int emp_track_lift(int axis, const int32_t *r_start, const int32_t *r_len, const
                    const int32_t *c_slice, const int32_t *comp_inst, int64_t n_runs, int H, int W, int Y, int X,
                    int slice0, int64_t inst_base, int32_t *work, uint64_t *out_key, int64_t *out_len,
                    int32_t *n_out, void *stream);
+/* emp_tile_lift  C5, Tiler.translate_rle_seg (empanada/inference/tile.py:122-168) for all slices of one tile: runs of
+ *                 every object merged as rle_encode of its flat TILE indices merges them, start mapped into the image
+ *                 frame ((start / tw + y0) * X + start % tw + x0), length kept; 2D positions, the slice stays with the
+ *                 object: key = (inst_base + comp_inst[comp]) << 40 | start2d.  work: emp_track_work_elems(n_runs). */
+int emp_tile_lift(const int32_t *r_start, const int32_t *r_len, const int32_t *r_comp, const int32_t *c_slice,
+                  const int32_t *comp_inst, int64_t n_runs, int tw, int X, int y0, int x0, int64_t inst_base,
+                  int32_t *work, uint64_t *out_key, int64_t *out_len, int32_t *n_out, void *stream);
 int emp_track_lift_yz(const int32_t *row_offsets, const int32_t *r_start, const int32_t *r_len,
                       const uint32_t *r_val, int64_t n_rows, int64_t n_runs, int Xl, int X, int x0,
                       int64_t inst_base, uint64_t *out_key, int64_t *out_len, void *stream);

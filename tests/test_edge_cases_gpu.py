@@ -215,3 +215,35 @@ def test_orthoplane_single_object_and_a_blind_plane():
     got, n, _ = _ortho_product(heads, shape, KW, 50, 3)
     exp, ne = _ortho_oracle(heads, shape, KW, 50, 3)
     assert n == ne == 0 and not got.any() and not exp.any()
+
+
+def test_degenerate_class_does_not_lose_the_volume():
+    """A stuff class seen by ONE plane only is voted empty; the reference (and empanada_amd.consensus, bug-compatible)
+    raises IndexError at the very end of the run (consensus.py:331-339).  The volume driver keeps the finished classes:
+    on_degenerate='zero' (default) warns and writes that class as zeros, 'raise' keeps the crash; the thing class is the
+    same volume either way.  pixel_vote_thr == 1 with a one-run object (UnboundLocalError out of join_ranges) likewise."""
+    from empanada_amd.inference import sharded
+    shape = (16, 20, 24)
+    div = 1000
+    vol = np.zeros(shape, np.int64)
+    vol[3:12, 4:14, 5:17] = 1 * div + 1                      # one thing object, seen by every plane
+    stuff = np.zeros(shape, np.int64)
+    stuff[2:6, 12:19, 2:10] = 2 * div                        # stuff class 2: only the xy plane will see it
+
+    def planes_of(with_stuff_in):
+        planes, base = {}, 0
+        for ax, axis in enumerate(('xy', 'xz', 'yz')):
+            v = vol + (stuff if axis in with_stuff_in else 0)
+            pan = torch.from_numpy(np.ascontiguousarray(np.moveaxis(v, ax, 0)).astype(np.int32)).cuda().view(torch.uint32)
+            planes[axis] = sharded.track_plane(pan, axis, shape, [1, 2], [1], div, 0.25, 0.25, inst_base=base)
+            base += planes[axis].n_inst
+        return planes
+
+    _, ok, _ = sharded.consensus_volume(planes_of(('xy', 'xz', 'yz')), shape, [1, 2], [1], 2, 0.75, False)
+    assert ok[2].dtype == torch.uint8 and int(ok[2].sum()) == int((stuff > 0).sum())
+    with pytest.warns(RuntimeWarning, match='class 2 is degenerate'):
+        cons, vols, _ = sharded.consensus_volume(planes_of(('xy',)), shape, [1, 2], [1], 2, 0.75, False)
+    assert not vols[2].any() and cons[2].n == 0
+    assert torch.equal(vols[1].view(torch.int32), ok[1].view(torch.int32)) and int((vols[1].view(torch.int32) == 1).sum()) == 9 * 10 * 12
+    with pytest.raises(IndexError):
+        sharded.consensus_volume(planes_of(('xy',)), shape, [1, 2], [1], 2, 0.75, False, on_degenerate='raise')

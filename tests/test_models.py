@@ -78,3 +78,62 @@ def test_forward_gpu_within_tolerance(name):
             continue
         tol = dense_tol(float(np.abs(ref).max()))
         assert float(np.abs(got - ref).max()) <= tol, (name, k, float(np.abs(got - ref).max()), tol)
+
+
+# ------------------------------------------------------------------ BASELINE configs[0] at its real size (512 x 512)
+MITO_DAMP = {'semantic_head': 1e-3, 'ins_center': 5e-2, 'ins_xy': 1.0}          # oracle/gen_golden_r4.py::DAMP
+MITO_ENGINE = dict(thing_list=[1], label_divisor=20000, stuff_area=64, void_label=0, nms_threshold=0.1, nms_kernel=7,
+                   confidence_thr=0.3, padding_factor=16, coarse_boundaries=True)
+
+
+def _mitonet():
+    m = synthesize_weights(PanopticDeepLabPR(**MITO)).eval()
+    with torch.no_grad():
+        for head, damp in MITO_DAMP.items():
+            getattr(m, head).head[1].weight.mul_(damp)
+    return m
+
+
+def _mito_input(g):
+    return ((torch.from_numpy(g['image_u8']).float() - 255 * 0.508979) / (255 * 0.148561))[None, None]
+
+
+def test_mitonet_512_cpu_matches_reference():
+    """cfg 1: the MitoNet configuration on one 512 x 512 tile, called as the Render engine calls it (render_steps 2,
+    1/4-resolution instance heads) -- this package's module on the host against the REFERENCE class's outputs."""
+    g = load_golden('mitonet_512')
+    with torch.no_grad():
+        out = _mitonet()(_mito_input(g), 2, False)
+    for k in ('sem_logits', 'ctr_hmp', 'offsets'):
+        ref = g[k]
+        assert out[k].shape == ref.shape
+        np.testing.assert_allclose(out[k].numpy(), ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+def test_mitonet_512_gpu_forward_and_render_engine():
+    """cfg 1 on the GPU: (a) the prepared model (hand-written kernels) within the D1 tolerance of the reference's
+    outputs -- PointRend re-predicts the 8192 most uncertain points per step, a different rounding can swap points at
+    the k-th uncertainty, so a few positions may keep the interpolated value; (b) PanopticDeepLabRenderEngine (coarse
+    instance heads, MitoNet engine parameters) against the REFERENCE engine's panoptic image of the same tile: the
+    same labels on all but a handful of pixels (the heads differ by fp32 rounding, which can move a nearest-centre
+    decision on a cell border)."""
+    from empanada_amd.inference.engines import PanopticDeepLabRenderEngine
+    g = load_golden('mitonet_512')
+    m = prepare_for_inference(_mitonet(), 'cuda')
+    x = _mito_input(g).cuda().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        out = m(x, 2, False)
+    for k in ('ctr_hmp', 'offsets'):
+        ref = g[k]
+        err = float(np.abs(out[k].float().cpu().numpy() - ref).max())
+        assert err <= dense_tol(float(np.abs(ref).max())), (k, err)
+    ref = g['sem_logits']
+    bad = np.abs(out['sem_logits'].float().cpu().numpy() - ref) > 10 * dense_tol(float(np.abs(ref).max()))
+    assert bad.mean() < 1e-3, bad.mean()
+    engine = PanopticDeepLabRenderEngine(m, **MITO_ENGINE)
+    pan = engine(_mito_input(g), (512, 512)).cpu().numpy().astype(np.int64)
+    exp = g['pan_seg']
+    assert pan.shape == exp.shape and len(np.unique(exp)) >= 10
+    assert (pan != exp).mean() < 2e-3, (pan != exp).mean()
+    assert set(np.unique(pan)) == set(np.unique(exp))
