@@ -228,7 +228,7 @@ def test_degenerate_class_does_not_lose_the_volume():
     vol = np.zeros(shape, np.int64)
     vol[3:12, 4:14, 5:17] = 1 * div + 1                      # one thing object, seen by every plane
     stuff = np.zeros(shape, np.int64)
-    stuff[2:6, 12:19, 2:10] = 2 * div                        # stuff class 2: only the xy plane will see it
+    stuff[2:6, 15:19, 2:10] = 2 * div                        # stuff class 2 (clear of the thing object)
 
     def planes_of(with_stuff_in):
         planes, base = {}, 0
