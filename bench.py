@@ -274,6 +274,7 @@ class Pipeline:
         hp, wp = dv.padded_shape(axis)
         for s in range(lo, hi, per):
             e = min(hi, s + per)
+            _hip.trace(f'forward {axis} [{s}, {e}) {"graph" if model is self.graphed else "eager"}')
             buf = model.input_buffer((e - s, 1, hp, wp), args=self.model_args) if model is self.graphed else None
             x = dv.batch(axis, s, e, out=buf)        # straight into the graph's input: no device-to-device copy
             if self.dtype != torch.float32:
@@ -419,6 +420,7 @@ def postprocess_planes(heads, shape3d, writer, stages, between=None, before=None
     `axis` is touched (the driver makes the post-processing stream wait for that plane's forward there).
     writer: {class: SlabWriter} or None.
     Returns (#consensus instances, {class: the rank's slab of that class's labelled volume on the device}, (z0, z1))."""
+    from empanada_amd import _hip
     from empanada_amd.inference import sharded
     planes, base = {}, 0
     for i, axis in enumerate(('xy', 'xz', 'yz')):
@@ -426,6 +428,7 @@ def postprocess_planes(heads, shape3d, writer, stages, between=None, before=None
         if before is not None:
             before(axis)
         h = heads[axis]
+        _hip.trace(f'postprocess {axis}')
         pan = sharded.sharded_panoptic_stack(h['sem'], h['ctr_hmp'], h['offsets'], coarse_boundaries=COARSE, **ENGINE)
         table, host = sharded.sharded_tables(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'])
         t1 = time.perf_counter()

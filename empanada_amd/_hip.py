@@ -39,6 +39,8 @@ SIGNATURES = {
     'emp_conv_bn_act_proj_nhwc': (_I, [_P, _P, _P, _P, _I] + [_I] * 10 + [_P, _I, _P, _P, _L, _P]),
     'emp_conv_k_slab': (_I, [_L, _I, _I, _I]),
     'emp_conv_k_slab_cin': (_I, [_L, _I, _I, _I, _I]),
+    'emp_conv_k_slab_geom': (_I, [_L, _I, _I, _I, _I, _I, _I, _I, _I]),
+    'emp_conv1x1_ws_eligible': (_I, [_L, _I, _I, _I, _I, _I, _I, _I]),
     'emp_gconv_chunk': (_I, [_I]),
     'emp_gconv3x3_bn_act_nhwc': (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     'emp_conv_bn_act_nhwc': (_I, [_P, _P, _P, _P, _P, _L, _I] + [_I] * 10 + [_P, _L, _P]),
@@ -161,6 +163,12 @@ PROFILE_SKIP = set()
 _TRACE = None
 if os.environ.get('EMP_TRACE_CALLS'):
     _TRACE = open(os.environ['EMP_TRACE_CALLS'], 'a', buffering=1)
+
+
+def trace(msg):
+    """marker line in the EMP_TRACE_CALLS log (no-op without it)"""
+    if _TRACE is not None:
+        _TRACE.write('# ' + msg + '\n')
 
 
 def call(name, *args, alg_bytes=None, alg_flops=None):
@@ -752,9 +760,14 @@ def wino4_conv_bn_act(x, U, tiles_dev, dil, scale=None, shift=None, relu=False, 
     return out
 
 
-def conv_k_slab(M, Cout, batch=1, has_residual=False, Cin=None):
-    """K-slab (16 or 32) emp_conv_bn_act_nhwc / emp_gemm_nt_batched use for an (M x Cout) output, `batch` GEMMs per
-    launch: fixes the summation order the oracle mirrors"""
+def conv_k_slab(M, Cout, batch=1, has_residual=False, Cin=None, geom=None, relu=False):
+    """K-slab (16, 32 or 64) emp_conv_bn_act_nhwc / emp_gemm_nt_batched use for an (M x Cout) output, `batch` GEMMs per
+    launch: fixes the summation order the oracle mirrors.  geom = (KH, KW, stride, pad) of a convolution: short-K
+    pointwise layers go to the weight-stationary kernel (emp_conv1x1.hip), which sums over 64-channel slabs."""
+    if geom is not None:
+        KH, KW, stride, pad = geom
+        return int(load().emp_conv_k_slab_geom(int(M), int(Cout), int(bool(has_residual)), int(Cin), int(KH), int(KW),
+                                               int(stride), int(pad), 2 if relu == 'gate' else int(bool(relu))))
     if Cin is not None:
         return int(load().emp_conv_k_slab_cin(int(M), int(Cout), int(batch), int(bool(has_residual)), int(Cin)))
     return int(load().emp_conv_k_slab(int(M), int(Cout), int(batch), int(bool(has_residual))))

@@ -594,6 +594,19 @@ extern "C" int emp_conv_k_slab_cin(int64_t M, int Cout, int batch, int has_resid
     return cg_plan(M, Cout, batch, has_residual != 0, true, true, Cin).slab;
 }
 
+// D4b (emp_conv1x1.hip): the weight-stationary kernel for short-K pointwise layers sums over 64-channel slabs
+extern "C" int emp_conv1x1_ws_eligible(int64_t M, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu);
+extern "C" int emp_conv1x1_ws_launch(const float *x, const float *w, const float *scale, const float *shift,
+                                     const float *res, int64_t res_ps, int relu, int64_t M, int Cin, int Cout,
+                                     float *out, int64_t out_ps, void *stream);
+
+extern "C" int emp_conv_k_slab_geom(int64_t M, int Cout, int has_residual, int Cin, int KH, int KW, int stride, int pad,
+                                    int relu)
+{
+    if (emp_conv1x1_ws_eligible(M, Cin, Cout, KH, KW, stride, pad, relu)) return 64;
+    return cg_plan(M, Cout, 1, has_residual != 0 && relu != 2, true, true, Cin).slab;
+}
+
 extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
                                     const float *residual, int64_t res_pixel_stride, int relu, int N, int H, int W,
                                     int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float *out,
@@ -621,6 +634,12 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
     g.M = (int64_t)N * OH * OW; g.out_ps = out_pixel_stride; g.res_ps = res_pixel_stride;
     g.x_bs = g.w_bs = g.out_bs = 0; g.tiles = nullptr; g.proj_w = nullptr; g.proj_out = nullptr; g.proj_n = 0; g.hw = 1;
     const bool res_vec_ok = (res_pixel_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
+    const bool io_vec_ok = res_vec_ok && (out_pixel_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                           (!scale || (reinterpret_cast<uintptr_t>(scale) & 15) == 0) &&
+                           (!shift || (reinterpret_cast<uintptr_t>(shift) & 15) == 0);
+    if (io_vec_ok && scale && shift && emp_conv1x1_ws_eligible(g.M, Cin, Cout, KH, KW, stride, pad, relu))
+        return emp_conv1x1_ws_launch(x, w_okkc, scale, shift, residual, res_pixel_stride, relu, g.M, Cin, Cout, out,
+                                     out_pixel_stride, stream);
     const CgPlan pl = cg_plan(g.M, Cout, 1, residual != nullptr && relu != 2, res_vec_ok, true, Cin);
     const bool narrow = pl.narrow, respf = pl.respf, bk16 = pl.slab == 16;
     EMP_REQUIRE((int64_t)pl.tiles_m * pl.tiles_n < (1LL << 28), "conv: too many tiles");

@@ -108,6 +108,15 @@ int emp_upsample_bilinear(const float *x, int N, int C, int h, int w, const int6
 int emp_conv_k_slab(int64_t M, int Cout, int batch, int has_residual);
 /* the same for a given Cin: Cin % 32 != 0 (RegNet widths 144, 1296: multiples of 16 only) always takes S = 16 */
 int emp_conv_k_slab_cin(int64_t M, int Cout, int batch, int has_residual, int Cin);
+/* D4b: short-K pointwise layers (1x1, stride 1, no padding, Cin 64 or 128, Cout a multiple of 128, at least 65 536
+ * output pixels: conv3 + identity and the shortcut projection of the ResNet bottleneck's layer1 / layer2,
+ * empanada/models/encoders/resnet.py:98-118) are computed by a weight-stationary kernel inside emp_conv_bn_act_nhwc
+ * (emp_conv1x1.hip: weights resident in LDS, activations straight into the MFMA operands, epilogue from the
+ * accumulators).  Its summation order is the D4 order with a K-slab of 64: slabs of 64 channels ascending, inside a
+ * slab j = 0..31: channel j, then channel 32 + j.  emp_conv_k_slab_geom returns the slab emp_conv_bn_act_nhwc will use
+ * for a given geometry (64 for these layers, else emp_conv_k_slab_cin's answer); relu as in emp_conv_bn_act_nhwc. */
+int emp_conv_k_slab_geom(int64_t M, int Cout, int has_residual, int Cin, int KH, int KW, int stride, int pad, int relu);
+int emp_conv1x1_ws_eligible(int64_t M, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu);
 /* relu == 2 selects the squeeze-excite gate epilogue (SqueezeExcite.forward, empanada/models/blocks.py:35-50:
  * x * sigmoid(conv(s) + bias)): out = residual * (1 / (1 + expf(-(acc * scale + shift)))), residual = the gated
  * tensor x (required); the division and the product are separate fp32 roundings, expf is the device library's;

@@ -494,6 +494,58 @@ def test_bn_act_into_channel_slice(hip):
 
 
 @pytest.mark.parametrize('cfg', [
+    # N, H, W, Cin, Cout, res, relu, out slice, res slice
+    (1, 255, 259, 64, 256, True, True, False, False),        # layer1 conv3 + identity + ReLU; last tile is partial
+    (2, 192, 192, 64, 256, False, False, False, False),      # layer1 shortcut projection (no residual, no ReLU)
+    (1, 256, 258, 128, 256, True, True, True, True),         # K = 128 (two slabs), output / residual = channel slices
+    (1, 300, 220, 128, 128, False, True, False, False),      # a single cout group
+    (1, 257, 256, 64, 384, True, False, False, False),       # three cout groups (grid of 240 blocks)
+])
+def test_conv1x1_weight_stationary(hip, cfg):
+    """D4b (emp_conv1x1.hip), reached through emp_conv_bn_act_nhwc for short-K pointwise layers with >= 65 536 pixels:
+    bit-exact against the C oracle with the K-slab the dispatcher reports (64), and the tiled kernel
+    (EMP_CONV_NO_WS is for A/B runs only) is NOT what ran: emp_conv_k_slab_geom says 64, which it never uses."""
+    from oracle import dense as OD
+    N, H, W, Cin, Cout, use_res, relu, out_slice, res_slice = cfg
+    M = N * H * W
+    assert hip.conv_k_slab(M, Cout, 1, use_res, Cin, geom=(1, 1, 1, 0), relu=relu) == 64
+    assert hip.conv_k_slab(M, Cout, 1, use_res, Cin, geom=(1, 1, 2, 0), relu=relu) in (16, 32)       # strided: tiled kernel
+    assert hip.conv_k_slab(1000, Cout, 1, use_res, Cin, geom=(1, 1, 1, 0), relu=relu) in (16, 32)    # too few pixels
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (1.0 / Cin ** 0.5)
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    res = torch.randn(N, Cout, H, W, generator=g) if use_res else None
+    w_okkc = w.permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    resd = None
+    if use_res:
+        if res_slice:
+            wide = torch.zeros(N, Cout + 64, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
+            wide[:, 32:32 + Cout] = res.cuda()
+            resd = wide[:, 32:32 + Cout]
+        else:
+            resd = res.cuda().contiguous(memory_format=torch.channels_last)
+    out = None
+    if out_slice:
+        buf = torch.full((N, Cout + 128, H, W), -7.0, device='cuda').contiguous(memory_format=torch.channels_last)
+        out = buf[:, 64:64 + Cout]
+    got = hip.conv_bn_act_nhwc(xd, w_okkc.cuda(), sc.cuda(), sh.cuda(), resd, relu, 1, 0, 1, out=out)
+    exp = OD.conv_bn_act_nhwc(x.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), sc.numpy(), sh.numpy(),
+                              res.permute(0, 2, 3, 1).numpy() if use_res else None, relu, 1, 0, 1, slab=64)
+    np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    if out_slice:
+        assert torch.all(buf[:, :64] == -7.0) and torch.all(buf[:, 64 + Cout:] == -7.0)
+    y = torch.nn.functional.conv2d(x, w) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if use_res:
+        y = y + res
+    if relu:
+        y = torch.relu(y)
+    bound = torch.nn.functional.conv2d(x.abs(), w.abs()) * sc.view(1, -1, 1, 1)
+    assert torch.all((got.cpu() - y).abs() <= 2e-6 * bound + 1e-6)
+
+
+@pytest.mark.parametrize('cfg', [
     # N, H, W, Cin, Cout, k, stride, pad, dil, res, relu, affine
     (2, 9, 11, 64, 128, 1, 1, 0, 1, True, True, True),
     (1, 12, 10, 32, 40, 3, 1, 1, 1, False, True, True),        # Cout not a tile multiple
