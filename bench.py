@@ -73,7 +73,8 @@ DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 
                  'emp_wino_output_transform', 'emp_wino4_input_transform', 'emp_wino4_output_transform',
                  'emp_wino3_input_transform', 'emp_wino3_output_transform',
                  'emp_pointwise_out_nhwc', 'emp_bn_relu_maxpool_nhwc', 'emp_slices_to_input', 'emp_gconv3x3_bn_act_nhwc',
-                 'emp_stem_conv7_bn_relu_maxpool', 'emp_logits_to_prob')
+                 'emp_stem_conv7_bn_relu_maxpool', 'emp_logits_to_prob', 'emp_pr_upsample2x', 'emp_pr_topk',
+                 'emp_pr_point_sample', 'emp_pr_scatter')
 MFMA_KERNELS = ('emp_conv_bn_act_nhwc', 'emp_conv_bn_act_proj_nhwc', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
                 'emp_gconv3x3_bn_act_nhwc')
 MFMA_F32_PEAK_TFLOPS = 157.3                   # dense fp32 matrix peak (MI355X_MICROARCH.md)

@@ -59,6 +59,11 @@ SIGNATURES = {
     'emp_bn_relu_maxpool_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'emp_stem_conv7_bn_relu_maxpool': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     'emp_logits_to_prob': (_I, [_P, _I, _I, _L, _P, _P]),
+    'emp_pr_upsample2x': (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    'emp_pr_topk_work_bytes': (_L, [_I, _L]),
+    'emp_pr_topk': (_I, [_P, _I, _L, _I, _P, _L, _P, _P]),
+    'emp_pr_point_sample': (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P]),
+    'emp_pr_scatter': (_I, [_P, _I, _P, _I, _I, _I, _L, _P, _P]),
     'emp_median_harden_stack': (_I, [_P, _I, _I, _L, _I, _F, _P, _P, _P]),
     'emp_median_step': (_I, [_c.POINTER(_P), _I, _L, _P, _P]),
     'emp_harden': (_I, [_P, _I, _I, _L, _F, _P, _P]),
@@ -701,6 +706,71 @@ def logits_to_prob(logits, out=None):
     if x.numel():
         call('emp_logits_to_prob', x.data_ptr(), N, C, H * W, out.data_ptr(), stream(), alg_bytes=8 * x.numel())
     return out
+
+
+# ----------------------------------------------------------------------------- D10: PointRend subdivision step
+def pr_upsample2x(logits):
+    """(N,C,h,w) fp32 planar -> (upsampled (N,C,2h,2w), uncertainty (N, 4hw)): F.interpolate(x2, bilinear,
+    align_corners=False) + calculate_uncertainty (point_rend.py:62-79, 244-248) in one pass"""
+    require_gpu()
+    N, C, h, w = logits.shape
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous()
+    up = torch.empty((N, C, 2 * h, 2 * w), dtype=torch.float32, device=logits.device)
+    unc = torch.empty((N, 4 * h * w), dtype=torch.float32, device=logits.device)
+    call('emp_pr_upsample2x', logits.data_ptr(), N, C, h, w, up.data_ptr(), unc.data_ptr(), stream(),
+         alg_bytes=4 * (logits.numel() + up.numel() + unc.numel()))
+    return up, unc
+
+
+def pr_topk(unc, k):
+    """(N, HW) fp32 -> (N, k) int32 pixel indices of the k largest per row (exact; ties at the k-th value to the lowest
+    indices; strictly larger ones first, each group in pixel order) -- torch.topk of point_rend.py:117"""
+    require_gpu()
+    N, HW = unc.shape
+    assert unc.is_cuda and unc.dtype == torch.float32 and unc.is_contiguous() and 1 <= k <= HW
+    wb = query('emp_pr_topk_work_bytes', N, HW)
+    work = torch.empty((wb,), dtype=torch.uint8, device=unc.device)
+    idx = torch.empty((N, k), dtype=torch.int32, device=unc.device)
+    call('emp_pr_topk', unc.data_ptr(), N, HW, int(k), _ptr(work), wb, _ptr(idx), stream(), alg_bytes=4 * 6 * unc.numel())
+    return idx
+
+
+def pr_point_sample(features, coarse, idx, H, W, ld):
+    """features (N,CF,Hf,Wf) channels_last, coarse (N,C,Hf,Wf) contiguous, idx (N,k) int32 on the (H,W) grid ->
+    (X0, X1) two (N*k, ld) matrices: X0 = [sampled features | sampled coarse | 0], X1 = [uninitialised | sampled
+    coarse | 0] (point_sample x 2 + the torch.cat of StandardPointHead.forward, point_rend.py:35-60,182-190)"""
+    require_gpu()
+    N, CF, Hf, Wf = features.shape
+    C = coarse.shape[1]
+    assert features.is_cuda and features.dtype == torch.float32 and features.stride(1) == 1
+    fps = features.stride(3)
+    assert features.stride(2) == Wf * fps and features.stride(0) == Hf * Wf * fps, "NHWC features required"
+    assert coarse.is_contiguous() and coarse.shape == (N, C, Hf, Wf) and idx.shape[0] == N and idx.dtype == torch.int32
+    k = idx.shape[1]
+    X0 = torch.empty((N * k, ld), dtype=torch.float32, device=features.device)
+    X1 = torch.empty((N * k, ld), dtype=torch.float32, device=features.device)
+    call('emp_pr_point_sample', features.data_ptr(), fps, coarse.data_ptr(), N, Hf, Wf, CF, C, _ptr(idx), k, int(H), int(W),
+         X0.data_ptr(), X1.data_ptr(), int(ld), stream(), alg_bytes=4 * N * k * (4 * CF + 2 * ld))
+    return X0, X1
+
+
+def pr_scatter(points, idx, logits):
+    """logits (N,C,H,W)[n, c, idx[n, j]] = points[n * k + j, c]   (scatter_ of point_rend.py:258-265)"""
+    require_gpu()
+    N, C, H, W = logits.shape
+    k = idx.shape[1]
+    assert points.shape[0] == N * k and points.stride(1) == 1 and logits.is_contiguous()
+    call('emp_pr_scatter', points.data_ptr(), points.stride(0), _ptr(idx), N, C, k, H * W, logits.data_ptr(), stream(),
+         alg_bytes=8 * N * k * C)
+    return logits
+
+
+def as_pixels(mat, cols=None):
+    """(P, ld) row-major matrix -> the (1, cols, P, 1) channels_last view emp_conv_bn_act_nhwc takes (a 1x1 convolution
+    over P 'pixels'); cols < ld gives the channel slice [0, cols)"""
+    P, ld = mat.shape
+    v = mat.view(1, P, 1, ld).permute(0, 3, 1, 2)
+    return v if cols is None else v[:, :cols]
 
 
 def stem_conv7_bn_relu_maxpool(x, w_tc, scale, shift):

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['emp_pixel.hip', 'emp_runs.hip', 'emp_ranges.hip', 'emp_tracks.hip', 'emp_dense.hip', 'emp_conv.hip', 'emp_conv1x1.hip', 'emp_gconv.hip', 'emp_stem.hip', 'emp_chain.cpp']
+SOURCES = ['emp_pixel.hip', 'emp_runs.hip', 'emp_ranges.hip', 'emp_tracks.hip', 'emp_dense.hip', 'emp_conv.hip', 'emp_conv1x1.hip', 'emp_gconv.hip', 'emp_stem.hip', 'emp_pointrend.hip', 'emp_chain.cpp']
 LIB = os.path.join(HERE, 'libemp_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17', '-Wno-unused-value',
          '-Wno-unused-result', '-Wno-inline-asm']

@@ -370,7 +370,7 @@ class PanopticBiFPNPR(PanopticBiFPN):
     def forward(self, x, render_steps: int = 2, interpolate_ins: bool = True):
         sem_x, ins_x = self._features(x)
         self.semantic_pr.subdivision_steps = render_steps
-        sem = self.semantic_pr(self.semantic_head(sem_x).float().contiguous(), sem_x.float().contiguous())
+        sem = self.semantic_pr(self.semantic_head(sem_x).float().contiguous(), sem_x.float())
         ctr, off = self.ins_center(ins_x), self.ins_xy(ins_x)
         return {'sem_logits': sem['sem_seg_logits'], 'ctr_hmp': self._up4(ctr) if interpolate_ins else ctr,
                 'offsets': self._up4(off) if interpolate_ins else off}

@@ -601,8 +601,58 @@ class PointRendSemSegHead(nn.Module):
         top2 = torch.topk(logits, k=2, dim=1)[0]
         return (top2[:, 1] - top2[:, 0]).unsqueeze(1)
 
+    hip_ops = False                                  # set by prepare_for_inference
+
+    def _hip_weights(self):
+        """Conv1d (Cout, Cin, 1) weights of the point head as (Cout, 1, 1, ld) with Cin zero-padded to a multiple of 16
+        (the K granule of emp_conv_bn_act_nhwc) + biases, built once"""
+        cached = getattr(self, '_hipw', None)
+        dev = self.point_head.predictor.weight.device
+        if cached is not None and cached[0].device == dev:
+            return cached
+        convs = [layer[0] for layer in self.point_head.fc_layers] + [self.point_head.predictor]
+        cin = convs[0].weight.shape[1]
+        ld = (cin + 15) // 16 * 16
+        out = []
+        for conv in convs:
+            w = torch.zeros((conv.weight.shape[0], 1, 1, ld), dtype=torch.float32, device=dev)
+            w[:, 0, 0, :conv.weight.shape[1]] = conv.weight.detach().float()[:, :, 0]
+            out += [w.contiguous(), conv.bias.detach().float().contiguous()]
+        self._hipw = out
+        self._hip_ld = ld
+        return out
+
+    def _forward_hip(self, coarse_logits, features):
+        """the eval branch on emp_pr_* + emp_conv_bn_act_nhwc (D10): features stay NHWC, nothing but the point
+        matrices (k points x 272 floats per image) is materialised"""
+        from .. import _hip
+        w = self._hip_weights()
+        ld = self._hip_ld
+        N, CF = features.shape[:2]
+        logits = coarse_logits
+        for _ in range(self.subdivision_steps):
+            logits, unc = _hip.pr_upsample2x(logits)
+            C, H, W = logits.shape[1:]
+            k = min(H * W, self.subdivision_num_points)
+            idx = _hip.pr_topk(unc, k)
+            X0, X1 = _hip.pr_point_sample(features, coarse_logits, idx, H, W, ld)
+            src, dst = X0, X1
+            for li in range(len(self.point_head.fc_layers)):
+                _hip.conv_bn_act_nhwc(_hip.as_pixels(src), w[2 * li], None, w[2 * li + 1], None, True,
+                                      out=_hip.as_pixels(dst, CF))
+                src, dst = dst, src
+            pts = torch.empty((src.shape[0], C), dtype=torch.float32, device=src.device)
+            _hip.conv_bn_act_nhwc(_hip.as_pixels(src), w[-2], None, w[-1], None, False, out=_hip.as_pixels(pts))
+            _hip.pr_scatter(pts, idx, logits)
+        return {'sem_seg_logits': logits}
+
     def forward(self, coarse_logits, features):
         assert not self.training, "only the inference path of PointRend is implemented"
+        if (self.hip_ops and coarse_logits.is_cuda and coarse_logits.dtype == torch.float32
+                and features.dtype == torch.float32 and features.stride(1) == 1
+                and self.point_head.fc_layers[0][0].weight.shape[0] == features.shape[1]):
+            return self._forward_hip(coarse_logits.contiguous(), features)
+        features = features.contiguous()               # the library path works on NCHW-contiguous features
         logits = coarse_logits.clone()
         for _ in range(self.subdivision_steps):
             logits = F.interpolate(logits, scale_factor=2.0, mode='bilinear', align_corners=False)
@@ -633,8 +683,9 @@ class PanopticDeepLabPR(PanopticDeepLab):
         sem_x = self.semantic_decoder(pyramid)
         ins_x = sem_x if self.instance_decoder is None else self.instance_decoder(pyramid)
         self.semantic_pr.subdivision_steps = render_steps
-        # the point head works on NCHW-contiguous fp32 features
-        sem = self.semantic_pr(self.semantic_head(sem_x).float().contiguous(), sem_x.float().contiguous())
+        # PointRend: on the GPU the features stay NHWC (emp_pr_point_sample gathers whole pixels); the library path
+        # makes them NCHW-contiguous itself
+        sem = self.semantic_pr(self.semantic_head(sem_x).float().contiguous(), sem_x.float())
         ctr, off = self.ins_center(ins_x), self.ins_xy(ins_x)
         return {'sem_logits': sem['sem_seg_logits'],
                 'ctr_hmp': self._up4(ctr) if interpolate_ins else ctr,

@@ -541,6 +541,36 @@ int emp_chain_class(int64_t D, const int64_t *bounds, const int64_t *comp_label,
                     const int64_t *tv, int64_t class_id, int64_t label_divisor, double iou_thr, double ioa_thr,
                     emp_lsap_fn lsap, int64_t *comp_final, int64_t *seen_labels, int64_t *n_seen);
 
+/* ---- D10: PointRend subdivision step (eval branch) ---------------------------------------------------------------
+ * replaces, per render step of the exported models' `forward(x, render_steps, interpolate_ins)`:
+ *   F.interpolate(x2, bilinear, align_corners=False)       empanada/models/point_rend.py:244-245
+ *   calculate_uncertainty + get_uncertain_point_coords_on_grid (torch.topk)   point_rend.py:62-79,97-125
+ *   point_sample (F.grid_sample, bilinear, align_corners=False, zeros) of features and coarse logits   :35-60,253-254
+ *   StandardPointHead (Conv1d + ReLU x num_fc, predictor; coarse logits re-fed to every layer)          :138-190
+ *   scatter_ of the point predictions into the upsampled logits                                          :258-265
+ * emp_pr_upsample2x  logits (N, C, h, w) planar -> out (N, C, 2h, 2w) and uncertainty (N, 4hw): -|l| for C == 1,
+ *                    second-largest minus largest logit otherwise.
+ * emp_pr_topk        idx (N, k) int32 = pixel indices of the k largest uncertainties of every image: exact (radix
+ *                    select); ties at the k-th value go to the lowest indices; order: the strictly larger ones in pixel
+ *                    order, then the ties in pixel order.  work: emp_pr_topk_work_bytes(N, HW) bytes.
+ * emp_pr_point_sample  features NHWC (N, Hf, Wf, CF), pixel stride feat_pixel_stride; coarse (N, C, Hf, Wf) planar;
+ *                    point p = n * k + j sits at the centre of pixel idx[p] of the (H, W) grid.  Writes row p of the
+ *                    MLP input matrix X0 (P, ld): channels [0, CF) sampled features, [CF, CF + C) sampled coarse logits,
+ *                    [CF + C, ld) zeros; and the channels [CF, ld) of X1 (the next layer's input, whose first CF
+ *                    channels the MLP layer writes).  ld % 16 == 0 so that emp_conv_bn_act_nhwc can consume it.
+ * the MLP            emp_conv_bn_act_nhwc(x = X as (1, P, 1, ld), w = (Cout, 1, 1, ld) zero-padded, shift = bias,
+ *                    relu, out = channel slice [0, Cout) of the other matrix): summation order of D4.
+ * emp_pr_scatter     logits[n, c, idx[p]] = points[p * ld_points + c].                                            */
+int emp_pr_upsample2x(const float *logits, int N, int C, int h, int w, float *out, float *uncertainty, void *stream);
+int64_t emp_pr_topk_work_bytes(int N, int64_t HW);
+int emp_pr_topk(const float *uncertainty, int N, int64_t HW, int k, void *work, int64_t work_bytes, int32_t *idx,
+                void *stream);
+int emp_pr_point_sample(const float *feat_nhwc, int64_t feat_pixel_stride, const float *coarse, int N, int Hf, int Wf,
+                        int CF, int C, const int32_t *idx, int k, int H, int W, float *X0, float *X1, int ld,
+                        void *stream);
+int emp_pr_scatter(const float *points, int ld_points, const int32_t *idx, int N, int C, int k, int64_t HW,
+                   float *logits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

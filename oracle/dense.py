@@ -419,3 +419,85 @@ def conv_bn_act_proj_nhwc(x_nhwc, w_okkc, scale, shift, relu, proj_w, proj_b=Non
             total = (total + np.float32(proj_b[q])).astype(np.float32)
         out[:, q] = total
     return np.ascontiguousarray(out.reshape(N, OH * OW, n).transpose(0, 2, 1)).reshape(N, n, OH, OW)
+
+
+# ----------------------------------------------------------------------------- D10: PointRend subdivision step
+def pr_upsample2x(x):
+    """F.interpolate(scale_factor=2, bilinear, align_corners=False) + calculate_uncertainty
+    (empanada/models/point_rend.py:62-79, 244-248), fp32 op for op as emp_pr_upsample2x documents it.
+    x (N,C,h,w) -> (up (N,C,2h,2w), uncertainty (N, 4hw))."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    N, C, h, w = x.shape
+    f = np.float32
+
+    def src(n_out, n_in):
+        s = (np.arange(n_out, dtype=np.float32) + f(0.5)) * f(0.5) - f(0.5)
+        s = np.maximum(s, f(0))
+        i0 = s.astype(np.int64)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = (s - i0.astype(np.float32)).astype(np.float32)
+        return i0, i1, l1, (f(1) - l1).astype(np.float32)
+
+    y0, y1, ly, ly0 = src(2 * h, h)
+    x0, x1, lx, lx0 = src(2 * w, w)
+    top = (lx0 * x[:, :, y0][:, :, :, x0]).astype(np.float32) + (lx * x[:, :, y0][:, :, :, x1]).astype(np.float32)
+    bot = (lx0 * x[:, :, y1][:, :, :, x0]).astype(np.float32) + (lx * x[:, :, y1][:, :, :, x1]).astype(np.float32)
+    up = ((ly0[:, None] * top).astype(np.float32) + (ly[:, None] * bot).astype(np.float32)).astype(np.float32)
+    if C == 1:
+        unc = -np.abs(up[:, 0])
+    else:
+        srt = np.sort(up, axis=1)
+        unc = (srt[:, -2] - srt[:, -1]).astype(np.float32)
+    return up, unc.reshape(N, -1).astype(np.float32)
+
+
+def pr_topk(unc, k):
+    """the k largest per row, exactly: ties at the k-th value go to the lowest indices; order = the strictly larger
+    ones in index order, then the ties in index order (what emp_pr_topk emits; torch.topk's own tie choice and order
+    are unspecified, point_rend.py:117 only uses the SET)"""
+    unc = np.asarray(unc, dtype=np.float32)
+    out = np.empty((unc.shape[0], k), dtype=np.int32)
+    for n in range(unc.shape[0]):
+        t = np.sort(unc[n])[-k]
+        gt = np.flatnonzero(unc[n] > t)
+        eq = np.flatnonzero(unc[n] == t)
+        out[n] = np.concatenate([gt, eq[:k - len(gt)]])
+    return out
+
+
+def pr_point_sample(feat_nhwc, coarse, idx, H, W, ld):
+    """point_sample (F.grid_sample bilinear, align_corners=False, zero padding; point_rend.py:35-60) of the features
+    (N,Hf,Wf,CF) and the coarse logits (N,C,Hf,Wf) at the centres of the grid points idx (N,k) of an (H,W) grid ->
+    X (N*k, ld) = [features | coarse | 0], the fp32 operations in emp_pr_point_sample's order."""
+    feat = np.ascontiguousarray(feat_nhwc, dtype=np.float32)
+    coarse = np.ascontiguousarray(coarse, dtype=np.float32)
+    N, Hf, Wf, CF = feat.shape
+    C = coarse.shape[1]
+    k = idx.shape[1]
+    f = np.float32
+    px, py = (idx % W).astype(np.float32), (idx // W).astype(np.float32)
+    cx = (f(0.5) / f(W) + px / f(W)).astype(np.float32)
+    cy = (f(0.5) / f(H) + py / f(H)).astype(np.float32)
+    gx, gy = (f(2) * cx - f(1)).astype(np.float32), (f(2) * cy - f(1)).astype(np.float32)
+    ix = (((gx + f(1)) * f(Wf) - f(1)) / f(2)).astype(np.float32)
+    iy = (((gy + f(1)) * f(Hf) - f(1)) / f(2)).astype(np.float32)
+    x0, y0 = np.floor(ix).astype(np.int64), np.floor(iy).astype(np.int64)
+    x1, y1 = x0 + 1, y0 + 1
+    wts = [((x1.astype(np.float32) - ix) * (y1.astype(np.float32) - iy)).astype(np.float32),
+           ((ix - x0.astype(np.float32)) * (y1.astype(np.float32) - iy)).astype(np.float32),
+           ((x1.astype(np.float32) - ix) * (iy - y0.astype(np.float32))).astype(np.float32),
+           ((ix - x0.astype(np.float32)) * (iy - y0.astype(np.float32))).astype(np.float32)]
+    nbr = [(y0, x0), (y0, x1), (y1, x0), (y1, x1)]
+    X = np.zeros((N * k, ld), dtype=np.float32)
+    n_of = np.repeat(np.arange(N), k)
+    for (yy, xx), wt in zip(nbr, wts):
+        ok = ((yy >= 0) & (yy < Hf) & (xx >= 0) & (xx < Wf)).ravel()
+        yc, xc = np.clip(yy, 0, Hf - 1).ravel(), np.clip(xx, 0, Wf - 1).ravel()
+        wv = np.where(ok, wt.ravel(), f(0)).astype(np.float32)
+        # the kernel skips neighbours outside the map; adding 0 * v here changes nothing but the sign of a zero,
+        # which a later addition of a non-zero term or the comparison as uint32 of +0 / -0 could expose: mask instead
+        fv = (feat[n_of, yc, xc] * wv[:, None]).astype(np.float32)
+        X[:, :CF] = np.where(ok[:, None], (X[:, :CF] + fv).astype(np.float32), X[:, :CF])
+        cv = (coarse[n_of, :, yc, xc] * wv[:, None]).astype(np.float32)
+        X[:, CF:CF + C] = np.where(ok[:, None], (X[:, CF:CF + C] + cv).astype(np.float32), X[:, CF:CF + C])
+    return X

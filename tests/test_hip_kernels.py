@@ -673,6 +673,122 @@ def test_logits_to_prob_kernel(hip, shape):
     assert torch.equal(y, got)
 
 
+# ------------------------------------------------------------------------------------------------ D10: PointRend step
+@pytest.mark.parametrize('shape', [(2, 1, 16, 20), (1, 3, 9, 7), (3, 1, 128, 128), (1, 5, 33, 1)])
+def test_pr_upsample2x(hip, shape):
+    """emp_pr_upsample2x: bit-exact against the oracle (same fp32 operations); within rounding of torch's
+    F.interpolate(x2, bilinear, align_corners=False) and of calculate_uncertainty (point_rend.py:62-79)."""
+    from oracle import dense as OD
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(sum(shape))) * 3
+    up, unc = hip.pr_upsample2x(x.cuda())
+    eu, ec = OD.pr_upsample2x(x.numpy())
+    np.testing.assert_array_equal(up.cpu().numpy().view(np.uint32), eu.view(np.uint32))
+    np.testing.assert_array_equal(unc.cpu().numpy().view(np.uint32), ec.view(np.uint32))
+    ref = torch.nn.functional.interpolate(x.cuda(), scale_factor=2.0, mode='bilinear', align_corners=False)
+    assert (up - ref).abs().max().item() <= 2e-6 * x.abs().max().item()
+
+
+@pytest.mark.parametrize('case', ['random', 'ties', 'all_equal', 'k_is_all', 'k_is_one', 'ragged'])
+def test_pr_topk(hip, case):
+    """emp_pr_topk: exactly the oracle's selection and order (the k largest, ties at the k-th value to the lowest
+    indices), and the same SET as torch.topk wherever the k-th value is unique."""
+    from oracle import dense as OD
+    g = torch.Generator().manual_seed(len(case))
+    N, HW, k = 3, 40000, 8192
+    u = -torch.rand((N, HW), generator=g) * 5
+    if case == 'ties':
+        u = torch.round(u * 4) / 4                       # 21 distinct values: thousands of ties at the threshold
+    elif case == 'all_equal':
+        u = torch.zeros((N, HW)) - 1.5
+    elif case == 'k_is_all':
+        N, HW, k = 2, 3000, 3000
+        u = u[:N, :HW].contiguous()
+    elif case == 'k_is_one':
+        k = 1
+    elif case == 'ragged':
+        N, HW, k = 5, 16384 * 2 + 77, 5000                # three chunks per image, the last almost empty
+        u = -torch.rand((N, HW), generator=g) * 5
+        u[2] = torch.round(u[2] * 8) / 8
+        u[3, 1000:30000] = float('-inf')
+    idx = hip.pr_topk(u.cuda(), k).cpu().numpy()
+    exp = OD.pr_topk(u.numpy(), k)
+    np.testing.assert_array_equal(idx, exp)
+    ref = torch.topk(u, k=k, dim=1)
+    for n in range(N):
+        assert len(set(idx[n].tolist())) == k
+        if case in ('random', 'k_is_one'):
+            assert set(idx[n].tolist()) == set(ref[1][n].tolist())
+        np.testing.assert_array_equal(np.sort(u[n].numpy()[idx[n]]), np.sort(ref[0][n].numpy()))
+
+
+@pytest.mark.parametrize('cfg', [(2, 12, 10, 256, 1, 300, 2), (1, 7, 9, 64, 3, 63, 4), (3, 16, 16, 128, 2, 1024, 2)])
+def test_pr_point_sample_and_scatter(hip, cfg):
+    """emp_pr_point_sample: bit-exact against the oracle; within rounding of F.grid_sample(bilinear,
+    align_corners=False) -- border points (zero padding) included; X1 carries the coarse channels only.
+    emp_pr_scatter: logits[n, c, idx] = points."""
+    from oracle import dense as OD
+    N, Hf, Wf, CF, C, k, up = cfg
+    H, W = Hf * up, Wf * up
+    g = torch.Generator().manual_seed(CF + k)
+    feat = torch.randn(N, CF, Hf, Wf, generator=g)
+    coarse = torch.randn(N, C, Hf, Wf, generator=g)
+    idx = torch.stack([torch.randperm(H * W, generator=g)[:k] for _ in range(N)]).to(torch.int32)
+    idx[:, 0], idx[:, 1] = 0, H * W - 1                   # corners: three of four neighbours outside the map
+    ld = (CF + C + 15) // 16 * 16
+    fd = feat.cuda().contiguous(memory_format=torch.channels_last)
+    X0, X1 = hip.pr_point_sample(fd, coarse.cuda(), idx.cuda(), H, W, ld)
+    exp = OD.pr_point_sample(feat.permute(0, 2, 3, 1).numpy(), coarse.numpy(), idx.numpy(), H, W, ld)
+    np.testing.assert_array_equal(X0.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    np.testing.assert_array_equal(X1[:, CF:].cpu().numpy().view(np.uint32), exp[:, CF:].view(np.uint32))
+    it = idx.long()
+    coords = torch.zeros(N, k, 2)
+    coords[:, :, 0] = 0.5 / W + (it % W).float() / float(W)
+    coords[:, :, 1] = 0.5 / H + torch.div(it, W, rounding_mode='floor').float() / float(H)
+    ref = torch.nn.functional.grid_sample(feat, 2.0 * coords.unsqueeze(2) - 1.0, mode='bilinear', align_corners=False)
+    ref = ref.squeeze(3).permute(0, 2, 1).reshape(N * k, CF)
+    assert (X0[:, :CF].cpu() - ref).abs().max().item() <= 4e-6 * feat.abs().max().item()
+    logits = torch.zeros(N, C, H, W, device='cuda')
+    pts = torch.randn(N * k, C, generator=g).cuda()
+    hip.pr_scatter(pts, idx.cuda(), logits)
+    want = torch.zeros(N, C, H * W).scatter_(2, it.unsqueeze(1).expand(-1, C, -1), pts.cpu().view(N, k, C).permute(0, 2, 1))
+    assert torch.equal(logits.cpu().view(N, C, -1), want)
+
+
+@pytest.mark.parametrize('C', [1, 3])
+def test_pointrend_head_hip_vs_library(hip, C):
+    """PointRendSemSegHead on the D10 kernels against the same module on the library calls the reference makes
+    (interpolate / topk / grid_sample / Conv1d / scatter_, point_rend.py:241-269), both on the GPU: the refined logits
+    agree to fp32 rounding except where a rounding difference swaps points at the k-th uncertainty; the point MLP is
+    bit-exact against the oracle's convolution (summation order of D4)."""
+    from oracle import dense as OD
+    from empanada_amd.models.panoptic_deeplab import PointRendSemSegHead
+    from empanada_amd.models import synthesize_weights
+    torch.manual_seed(C)
+    head = synthesize_weights(PointRendSemSegHead(256, C, subdivision_num_points=2048)).eval().cuda()
+    N, hf, wf = 2, 24, 20
+    feats = torch.randn(N, 256, hf, wf, device='cuda').contiguous(memory_format=torch.channels_last)
+    coarse = torch.randn(N, C, hf, wf, device='cuda')
+    with torch.no_grad():
+        head.hip_ops = False
+        ref = head(coarse, feats)['sem_seg_logits']
+        head.hip_ops = True
+        got = head(coarse, feats)['sem_seg_logits']
+        again = head(coarse, feats)['sem_seg_logits']
+    assert got.shape == ref.shape == (N, C, 4 * hf, 4 * wf) and torch.equal(got, again)
+    bad = (got - ref).abs() > 1e-4 * ref.abs().max() + 1e-5
+    assert bad.float().mean().item() < 2e-3, bad.float().mean().item()
+    # first MLP layer against the oracle's convolution on the sampled matrix
+    w = head._hip_weights()
+    up, unc = hip.pr_upsample2x(coarse)
+    idx = hip.pr_topk(unc, min(4 * hf * wf, 2048))
+    X0, X1 = hip.pr_point_sample(feats, coarse, idx, 2 * hf, 2 * wf, head._hip_ld)
+    hip.conv_bn_act_nhwc(hip.as_pixels(X0), w[0], None, w[1], None, True, out=hip.as_pixels(X1, 256))
+    P = X0.shape[0]
+    exp = OD.conv_bn_act_nhwc(X0.cpu().numpy().reshape(1, P, 1, -1), w[0].cpu().numpy(), None, w[1].cpu().numpy(), None,
+                              True, slab=hip.conv_k_slab(P, 256, 1, False, head._hip_ld))
+    np.testing.assert_array_equal(X1[:, :256].cpu().numpy().view(np.uint32), exp.reshape(P, 256).view(np.uint32))
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 64), (1, 37, 45), (3, 130, 70), (1, 7, 9), (2, 256, 320), (1, 1, 1)])
 def test_stem_conv7_bn_relu_maxpool(hip, shape):
     """emp_stem_conv7_bn_relu_maxpool (D9): bit-exact against the oracle (fma chain over the 49 taps in raster order,
