@@ -732,7 +732,7 @@ def test_pr_point_sample_and_scatter(hip, cfg):
     g = torch.Generator().manual_seed(CF + k)
     feat = torch.randn(N, CF, Hf, Wf, generator=g)
     coarse = torch.randn(N, C, Hf, Wf, generator=g)
-    idx = torch.stack([torch.randperm(H * W, generator=g)[:k] for _ in range(N)]).to(torch.int32)
+    idx = torch.stack([torch.randperm(H * W - 2, generator=g)[:k] + 1 for _ in range(N)]).to(torch.int32)   # distinct
     idx[:, 0], idx[:, 1] = 0, H * W - 1                   # corners: three of four neighbours outside the map
     ld = (CF + C + 15) // 16 * 16
     fd = feat.cuda().contiguous(memory_format=torch.channels_last)
