@@ -721,7 +721,7 @@ def test_pr_topk(hip, case):
         np.testing.assert_array_equal(np.sort(u[n].numpy()[idx[n]]), np.sort(ref[0][n].numpy()))
 
 
-@pytest.mark.parametrize('cfg', [(2, 12, 10, 256, 1, 300, 2), (1, 7, 9, 64, 3, 63, 4), (3, 16, 16, 128, 2, 1024, 2)])
+@pytest.mark.parametrize('cfg', [(2, 12, 10, 256, 1, 300, 2), (1, 7, 9, 64, 3, 63, 4), (3, 16, 16, 128, 2, 1000, 2)])
 def test_pr_point_sample_and_scatter(hip, cfg):
     """emp_pr_point_sample: bit-exact against the oracle; within rounding of F.grid_sample(bilinear,
     align_corners=False) -- border points (zero padding) included; X1 carries the coarse channels only.
