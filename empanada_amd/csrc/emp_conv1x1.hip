@@ -18,10 +18,10 @@
 //     staged in that permuted row order, so that in the epilogue lane c holds FOUR CONSECUTIVE couts of a pixel in the
 //     same register index of its four tiles -- residual loads and output stores are float4 per lane, 512 contiguous
 //     bytes per half-wave, straight from / to the accumulators (no LDS transpose);
-//   * ONE wave per SIMD with the whole 512-entry register file (two waves of 256 spill: 64 accumulators + 64 residual
-//     + 32-64 operand registers + fragments): the latency of a tile's operands is hidden by software pipelining
-//     instead -- the loads of the NEXT tile (activations and residual, 24-32 KB per wave, ~100 KB in flight per CU) are
-//     issued before the 128-256 MFMAs of the current one.
+//   * ONE wave per SIMD with the whole 512-entry register file (two waves of 256 spill), software-pipelined over two
+//     register sets: a tile's residual and the NEXT tile's activations are requested a whole matrix phase (128-256
+//     MFMAs, 3-7 us) before they are consumed (~100 KB in flight per CU), and the epilogue of tile i - 1 is issued
+//     in the shadow of tile i's MFMAs (two accumulator sets).
 // Summation order per output: one fmaf chain from +0 over 64-channel slabs ascending, inside a slab j = 0..31:
 // channel j, then channel 32 + j -- the order of emp_conv_bn_act_nhwc with a K-slab of 64 (emp_conv_k_slab_geom);
 // oracle/dense.py::conv_bn_act_nhwc(slab=64) reproduces it bit for bit.
@@ -77,35 +77,26 @@ __global__ __launch_bounds__(PW_THREADS, 1) void conv1x1_ws_kernel(PwGeom g)
     const int64_t stride_t = (int64_t)g.pix_blocks * (PW_THREADS / 64);
     const float *Bl = &Bs[r * LD + hh * 32];           // the lane's row of tile 0, its half of a slab
 
-    // operands of a tile: A = 128 contiguous bytes per lane and slab (rows past M re-read the last pixel, masked at the
-    // store); residual of the lane's 16 (pixel, 4 couts) outputs
-    auto load_tile = [&](int64_t t, float4 (&a)[KS][8], float4 (&rs)[RES ? 16 : 1]) {
-        const int64_t p0 = t * PW_ROWS;
-        const int64_t pa = (p0 + r < g.M) ? p0 + r : g.M - 1;
+    // ---- the pieces of a tile's life --------------------------------------------------------------------------
+    // A = 128 contiguous bytes per lane and slab
+    auto load_a = [&](int64_t t, float4 (&a)[KS][8]) {
+        const int64_t pa = t * PW_ROWS + r;            // (only full tiles come through here)
         const float *ap = g.x + pa * CIN + hh * 32;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int q = 0; q < 8; ++q) a[s][q] = *reinterpret_cast<const float4 *>(ap + 64 * s + 4 * q);
+    };
+    // residual of the lane's 16 (pixel, 4 couts) outputs
+    auto load_rs = [&](int64_t t, float4 (&rs)[RES ? 16 : 1]) {
         if constexpr (RES) {
+            const float *rp = g.res + (t * PW_ROWS + 4 * hh) * g.res_ps + co;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                int64_t p = p0 + (q & 3) + 8 * (q >> 2) + 4 * hh;
-                p = p < g.M ? p : g.M - 1;             // no branch around a load: the loop body stays straight-line, so
-                rs[q] = *reinterpret_cast<const float4 *>(g.res + p * g.res_ps + co);   // vmcnt waits stay partial
-            }
+            for (int q = 0; q < 16; ++q)
+                rs[q] = *reinterpret_cast<const float4 *>(rp + (int64_t)((q & 3) + 8 * (q >> 2)) * g.res_ps);
         }
     };
-
-    float4 a[KS][8], rs[RES ? 16 : 1], a_nx[KS][8], rs_nx[RES ? 16 : 1];
-    int64_t t = (int64_t)pb * (PW_THREADS / 64) + wave;
-    if (t < n_tiles) load_tile(t, a, rs);
-    for (; t < n_tiles; t += stride_t) {
-        const int64_t p0 = t * PW_ROWS;
-        const bool more = t + stride_t < n_tiles;      // wave-uniform
-        load_tile(more ? t + stride_t : t, a_nx, rs_nx);         // in flight during this tile's matrix work (the last
-                                                                 // tile re-requests itself: no branch in the body)
-        f32x16 acc[4];
+    auto mma = [&](f32x16 (&acc)[4], const float4 (&a)[KS][8]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -132,41 +123,89 @@ __global__ __launch_bounds__(PW_THREADS, 1) void conv1x1_ws_kernel(PwGeom g)
                     }
                 }
             }
-        // ---- epilogue straight from the accumulators: register q of tile j = pixel row(q, hh), cout co + j
-        float4 o[16];
+    };
+    // epilogue straight from the accumulators: register q of tile j = pixel row(q, hh), cout co + j
+    auto outv = [&](const f32x16 (&acc)[4], const float4 (&rs)[RES ? 16 : 1], int q) {
+        float v[4] = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float v[4] = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);
-            if constexpr (RES) {
-                v[0] = __fadd_rn(v[0], rs[q].x); v[1] = __fadd_rn(v[1], rs[q].y);
-                v[2] = __fadd_rn(v[2], rs[q].z); v[3] = __fadd_rn(v[3], rs[q].w);
-            }
-            if constexpr (RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            o[q] = make_float4(v[0], v[1], v[2], v[3]);
+        for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(__fmul_rn(v[e], sc[e]), sh[e]);
+        if constexpr (RES) {
+            v[0] = __fadd_rn(v[0], rs[q].x); v[1] = __fadd_rn(v[1], rs[q].y);
+            v[2] = __fadd_rn(v[2], rs[q].z); v[3] = __fadd_rn(v[3], rs[q].w);
         }
-        float *op = g.out + (p0 + 4 * hh) * g.out_ps + co;
-        if (p0 + PW_ROWS <= g.M) {                     // wave-uniform: every tile but the last of the launch
+        if constexpr (RELU) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                *reinterpret_cast<float4 *>(op + (int64_t)((q & 3) + 8 * (q >> 2)) * g.out_ps) = o[q];
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    auto epi = [&](const f32x16 (&acc)[4], const float4 (&rs)[RES ? 16 : 1], int64_t t) {       // full tiles
+        float *op = g.out + (t * PW_ROWS + 4 * hh) * g.out_ps + co;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            *reinterpret_cast<float4 *>(op + (int64_t)((q & 3) + 8 * (q >> 2)) * g.out_ps) = outv(acc, rs, q);
+    };
+
+    // ---- full tiles, software-pipelined over two register sets: in phase i the residual of tile i and the activations
+    // of tile i + 1 are requested, then the MFMAs of tile i (into acc[i % 2]) and the epilogue of tile i - 1 (out of
+    // acc[(i - 1) % 2]) sit in ONE basic block, so that the scheduler can slot the epilogue's vector ALU work and
+    // stores between the matrix instructions -- with one wave per SIMD nothing else would fill the matrix pipe's
+    // shadow.  Loads are consumed one phase (128-256 MFMAs, 3-7 us) after they were issued.
+    const int64_t n_full = g.M / PW_ROWS;
+    const int64_t t_first = (int64_t)pb * (PW_THREADS / 64) + wave;
+    if (t_first < n_full) {
+        const int64_t m = (n_full - t_first + stride_t - 1) / stride_t;       // tiles of this wave
+        auto tile = [&](int64_t i) { return t_first + (i < m ? i : m - 1) * stride_t; };   // (past the end: re-request the last)
+        float4 a0[KS][8], a1[KS][8], rs0[RES ? 16 : 1], rs1[RES ? 16 : 1];
+        f32x16 acc0[4], acc1[4];
+        load_a(tile(0), a0);
+        load_rs(tile(0), rs0);
+        load_a(tile(1), a1);
+        mma(acc0, a0);
+        int64_t i = 1;
+        for (; i + 1 < m; i += 2) {
+            load_rs(tile(i), rs1);
+            load_a(tile(i + 1), a0);
+            mma(acc1, a1);
+            epi(acc0, rs0, tile(i - 1));
+            load_rs(tile(i + 1), rs0);
+            load_a(tile(i + 2), a1);
+            mma(acc0, a0);
+            epi(acc1, rs1, tile(i));
+        }
+        if (i < m) {                                   // one more tile (odd index), then its epilogue
+            load_rs(tile(i), rs1);
+            mma(acc1, a1);
+            epi(acc0, rs0, tile(i - 1));
+            epi(acc1, rs1, tile(i));
         } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (p0 + (q & 3) + 8 * (q >> 2) + 4 * hh < g.M)
-                    *reinterpret_cast<float4 *>(op + (int64_t)((q & 3) + 8 * (q >> 2)) * g.out_ps) = o[q];
+            epi(acc0, rs0, tile(i - 1));
         }
+    }
+    // ---- the launch's one partial tile (M % 32 rows), by the wave whose turn it would be: clamped loads, masked stores
+    if (n_full < n_tiles && (n_full - t_first) % stride_t == 0 && n_full >= t_first) {
+        const int64_t p0 = n_full * PW_ROWS;
+        const int64_t pa = (p0 + r < g.M) ? p0 + r : g.M - 1;
+        const float *ap = g.x + pa * CIN + hh * 32;
+        float4 a[KS][8], rs[RES ? 16 : 1];
+        f32x16 acc[4];
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[s][q] = a_nx[s][q];
+            for (int q = 0; q < 8; ++q) a[s][q] = *reinterpret_cast<const float4 *>(ap + 64 * s + 4 * q);
         if constexpr (RES) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) rs[q] = rs_nx[q];
+            for (int q = 0; q < 16; ++q) {
+                int64_t p = p0 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+                p = p < g.M ? p : g.M - 1;
+                rs[q] = *reinterpret_cast<const float4 *>(g.res + p * g.res_ps + co);
+            }
+        }
+        mma(acc, a);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t p = p0 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+            if (p < g.M) *reinterpret_cast<float4 *>(g.out + p * g.out_ps + co) = outv(acc, rs, q);
         }
     }
 }

@@ -30,7 +30,7 @@ def main():
           f"{len(sel)} dispatches\n")
     mine = ('median_harden', 'median_step', 'find_centers', 'sort_centers', 'group_pixels', 'fuse_', 'row_runs',
             'runs_fix', 'label_', 'overlap_next', 'fill_', 'scan_', 'vote_', 'pair_inter', 'box_pairs', 'cells_', 'dwconv_', 'bn_act_', 'rle_', 'conv_igemm', 'wino_', 'upsample_nhwc', 'upsample_planar',
-            'group_centers', 'wino3_', 'wino4_', 'pointwise_out', 'bn_relu_maxpool', 'slices_to_input', 'gconv3x3', 'trk_', 'triplet', 'stem7')
+            'group_centers', 'conv1x1_ws', 'pr_hist', 'pr_pick', 'pr_count', 'pr_emit', 'pr_init', 'pr_sample', 'pr_scatter', 'pr_upsample', 'wino3_', 'wino4_', 'pointwise_out', 'bn_relu_maxpool', 'slices_to_input', 'gconv3x3', 'trk_', 'triplet', 'stem7')
     print("| kernel | total ms | calls | avg us | % busy | hand-written |\n|---|---|---|---|---|---|")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
         hw = any(m in k for m in mine) and 'at::' not in k
