@@ -32,7 +32,7 @@ def load(d, counter):
 
 def main():
     fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
-    mine = ('conv_igemm', 'wino_', 'wino3_', 'wino4_', 'pointwise_out', 'bn_relu_maxpool', 'slices_to_input', 'dwconv', 'bn_act', 'upsample_', 'median', 'find_centers', 'group_pixels', 'fuse_',
+    mine = ('conv_igemm', 'conv1x1_ws', 'stem7', 'pr_', 'logits_to_prob', 'gconv3x3', 'wino_', 'wino3_', 'wino4_', 'pointwise_out', 'bn_relu_maxpool', 'slices_to_input', 'dwconv', 'bn_act', 'upsample_', 'median', 'find_centers', 'group_pixels', 'fuse_',
             'row_runs', 'label_', 'overlap_next', 'fill_table', 'fill_u32', 'trk_', 'trip_', 'vote_', 'pair_inter', 'box_pairs')
     print("# rocprofv3 PMC passes over bench.py (timed pass only): HBM traffic per launch\n")
     print("traffic = 2 x FETCH_SIZE + WRITE_SIZE (KiB), separate passes\n")
