@@ -61,13 +61,17 @@ ALG_BYTES = {
 # HBM traffic / algorithmic bytes from rocprofv3 PMC passes over this script (2 x FETCH_SIZE + WRITE_SIZE, calibrated
 # on known byte counts), collected OFFLINE with the tuned implementation choices replayed: --pmc cannot run inside this
 # script.  The JSON line labels the figure `traffic_source: offline PMC`.
+# emp_conv_bn_act_nhwc (the dominant kernel): the DEFAULT workload's own counters, round 3
+# (profiles/r3_pmc_bench_ortho1024.md: 9.075e12 B of traffic over the 4 224 launches of a pass -- tiled kernel, its
+# residual-prefetch and 64-wide variants, the weight-stationary 1x1 kernel at 1.00-1.07 -- against 7.672e12 algorithmic).
 PMC_TRAFFIC_RATIO = {
-    'emp_conv_bn_act_nhwc': 1.17, 'emp_bn_act_nhwc': 1.0, 'emp_dwconv_nhwc': 1.06, 'emp_upsample_bilinear': 1.2,
+    'emp_conv_bn_act_nhwc': 1.18, 'emp_bn_act_nhwc': 1.0, 'emp_dwconv_nhwc': 1.06, 'emp_upsample_bilinear': 1.2,
     'emp_median_harden_stack': 1.0, 'emp_find_centers': 1.14, 'emp_group_pixels': 1.26, 'emp_fuse_apply': 1.0,
     'emp_runs_count': 1.0, 'emp_runs_extract': 1.04,
 }
-PMC_SOURCE = ('offline PMC ratio x algorithmic bytes (profiles/r2_pmc_bench_ortho512.md: same pixels per launch as this '
-              'workload; r1_pmc_postproc_256x512x512.md for the per-voxel kernels)')
+PMC_SOURCE = ('offline PMC ratio x algorithmic bytes (profiles/r3_pmc_bench_ortho1024.md: rocprofv3 --pmc FETCH_SIZE / '
+              'WRITE_SIZE passes over this workload at --size 1024; the other dense kernels r2_pmc_bench_ortho512.md, '
+              'the per-voxel kernels r1_pmc_postproc_256x512x512.md)')
 DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 'emp_conv_bn_act_nhwc',
                  'emp_conv_bn_act_proj_nhwc', 'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
                  'emp_wino_output_transform', 'emp_wino4_input_transform', 'emp_wino4_output_transform',
@@ -195,12 +199,13 @@ class Pipeline:
         # pass waits for.  The call is captured once per input shape in a HIP graph and replayed (one launch); the
         # forwards whose kernels are individually event-timed for the roofline block run un-captured.
         self.graphed = None
-        # PointRend models: a graph REPLAY that follows an eager forward of the same model has ended in a GPU memory
-        # fault (tools/diag_mitonet.py: eager, capture, replays, eager, replay, eager, replay -> fault; 14 replays
-        # alone and 14 eager forwards alone are clean).  Until the cause is known the order is
-        # arranged so that it cannot occur: warm-up and the event-timed pass run eagerly, the graphs are captured
-        # after them (inside the timed region) and nothing runs eagerly between replays.
-        self.graphs_enabled = not MODEL_ARGS.get(args.model)
+        # With the PointRend model a graph REPLAY that follows an eager forward of the same model has ended in a GPU
+        # memory fault (tools/diag_mitonet.py: eager, capture, replays, eager, replay, eager, replay -> fault; 14 replays
+        # alone and 14 eager forwards alone are clean).  PanopticDeepLab has run that order hundreds
+        # of times without it, but until the cause is known NO model is run that way: warm-up and the event-timed pass
+        # are eager, the graphs are captured after them (inside the timed region: one warm-up call + the capture, once
+        # per input shape) and nothing runs eagerly between replays.
+        self.graphs_enabled = False
         if not args.no_graph:
             from empanada_amd.models.graphed import GraphedForward
             self.graphed = GraphedForward(self.model, warmup=1, max_graphs=4, clone_outputs=False)
@@ -607,7 +612,7 @@ def main_orthoplane(args, device, rank, world):
     barrier()
     _hip.PROFILE = {}
     pipe.dense_profile_left = 3                      # the dense-path calls of the first pass's three forwards are timed
-    pipe.graphs_enabled = True                       # (PointRend models: captured only now, see Pipeline.__init__)
+    pipe.graphs_enabled = True                       # captured from the 4th forward on (see Pipeline.__init__)
     stages, chks = {}, []
     t0 = time.perf_counter()
     first = None
@@ -817,6 +822,7 @@ def main_stack(args, device, rank, world):
     barrier()
     _hip.PROFILE = {}
     pipe.dense_profile_left = 1 if not args.no_pipeline else args.steps
+    pipe.graphs_enabled = True
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
     chks = []
     t0 = time.perf_counter()

@@ -596,7 +596,7 @@ extern "C" int emp_conv_k_slab_cin(int64_t M, int Cout, int batch, int has_resid
 
 // D4b (emp_conv1x1.hip): the weight-stationary kernel for short-K pointwise layers sums over 64-channel slabs
 extern "C" int emp_conv1x1_ws_eligible(int64_t M, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu);
-extern "C" int emp_conv1x1_ws_launch(const float *x, const float *w, const float *scale, const float *shift,
+extern "C" __attribute__((visibility("hidden"))) int emp_conv1x1_ws_launch(const float *x, const float *w, const float *scale, const float *shift,
                                      const float *res, int64_t res_ps, int relu, int64_t M, int Cin, int Cout,
                                      float *out, int64_t out_ps, void *stream);
 

@@ -222,7 +222,7 @@ extern "C" int emp_conv1x1_ws_eligible(int64_t M, int Cin, int Cout, int KH, int
 }
 
 // called by emp_conv_bn_act_nhwc for eligible shapes (pointers and strides already checked for 16-byte alignment)
-extern "C" int emp_conv1x1_ws_launch(const float *x, const float *w, const float *scale, const float *shift,
+extern "C" __attribute__((visibility("hidden"))) int emp_conv1x1_ws_launch(const float *x, const float *w, const float *scale, const float *shift,
                                      const float *res, int64_t res_ps, int relu, int64_t M, int Cin, int Cout,
                                      float *out, int64_t out_ps, void *stream)
 {
