@@ -90,10 +90,14 @@ __device__ __forceinline__ uint32_t pr_key(float v)
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// state = (prefix 0, mask 0, remaining k, 0) per image, histograms = 0.  A kernel, not hipMemsetAsync: a memset NODE of
+// a captured HIP graph went wrong on replay once other launches had run in between -- this step
+// sits inside the captured forward.
 __global__ void pr_init_kernel(uint32_t *state, int N, uint32_t k)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < N) state[4 * n + 2] = k;                   // everything else was zeroed by the launcher's memset
+    const int64_t total = (int64_t)N * (4 + 256);      // state (N, 4) followed by hist (N, 256)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        state[i] = (i < (int64_t)N * 4 && (i & 3) == 2) ? k : 0u;
 }
 
 // per-image selection state: [0] prefix, [1] mask, [2] how many of the k are still to be found among the elements
@@ -254,10 +258,7 @@ extern "C" int emp_pr_topk(const float *uncertainty, int N, int64_t HW, int k, v
     const int G = (int)emp_cdiv(HW, PR_CHUNK);
     hipStream_t st = emp_stream(stream);
     uint32_t *state = reinterpret_cast<uint32_t *>(work), *hist = state + (int64_t)N * 4, *counts = hist + (int64_t)N * 256;
-    // state = (prefix 0, mask 0, remaining k, 0) per image; hist = 0
-    if (hipMemsetAsync(state, 0, sizeof(uint32_t) * ((int64_t)N * 4 + (int64_t)N * 256), st) != hipSuccess)
-        EMP_FAIL(EMP_ELAUNCH, "pr_topk: memset");
-    hipLaunchKernelGGL(pr_init_kernel, dim3((unsigned)emp_cdiv(N, 256)), dim3(256), 0, st, state, N, (uint32_t)k);
+    hipLaunchKernelGGL(pr_init_kernel, dim3(emp_grid((int64_t)N * 260, 256, 1024)), dim3(256), 0, st, state, N, (uint32_t)k);
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         hipLaunchKernelGGL(pr_hist_kernel, dim3(G, N), dim3(PR_BLOCK), 0, st, uncertainty, HW, shift, state, hist);
