@@ -199,13 +199,10 @@ class Pipeline:
         # pass waits for.  The call is captured once per input shape in a HIP graph and replayed (one launch); the
         # forwards whose kernels are individually event-timed for the roofline block run un-captured.
         self.graphed = None
-        # With the PointRend model a graph REPLAY that follows an eager forward of the same model has ended in a GPU
-        # memory fault (tools/diag_mitonet.py: eager, capture, replays, eager, replay, eager, replay -> fault; 14 replays
-        # alone and 14 eager forwards alone are clean).  PanopticDeepLab has run that order hundreds
-        # of times without it, but until the cause is known NO model is run that way: warm-up and the event-timed pass
-        # are eager, the graphs are captured after them (inside the timed region: one warm-up call + the capture, once
-        # per input shape) and nothing runs eagerly between replays.
-        self.graphs_enabled = False
+        # (round 3: a hipMemsetAsync inside the captured PointRend step -- a memset NODE of the graph -- went wrong on
+        # replay once other launches had run in between, up to GPU memory faults; tools/diag_mitonet.py, DESIGN.md
+        # section 9.  The captured forward contains kernels only now.)
+        self.graphs_enabled = True
         if not args.no_graph:
             from empanada_amd.models.graphed import GraphedForward
             self.graphed = GraphedForward(self.model, warmup=1, max_graphs=4, clone_outputs=False)
@@ -612,7 +609,6 @@ def main_orthoplane(args, device, rank, world):
     barrier()
     _hip.PROFILE = {}
     pipe.dense_profile_left = 3                      # the dense-path calls of the first pass's three forwards are timed
-    pipe.graphs_enabled = True                       # captured from the 4th forward on (see Pipeline.__init__)
     stages, chks = {}, []
     t0 = time.perf_counter()
     first = None
@@ -822,7 +818,6 @@ def main_stack(args, device, rank, world):
     barrier()
     _hip.PROFILE = {}
     pipe.dense_profile_left = 1 if not args.no_pipeline else args.steps
-    pipe.graphs_enabled = True
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
     chks = []
     t0 = time.perf_counter()
