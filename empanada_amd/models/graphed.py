@@ -9,6 +9,12 @@ so they are captured like torch's own) and replays it with a single launch after
 
 Outputs are cloned out of the graph's static buffers, because the engines keep the head tensors of the last
 ``median_kernel_size`` slices in their queue.
+
+Caveat found in round 3: on ROCm 7.2 a MEMSET node inside a captured graph goes wrong on replay
+once other kernels have been launched between replays (wrong results, then GPU memory faults).  This package's own
+capturable entries zero with kernels for that reason; library ops that call ``hipMemsetAsync`` internally
+(``torch.topk`` on large rows does) must not be captured -- the PointRend models are safe on the fp32 GPU path (D10
+kernels) and must NOT be wrapped in ``GraphedForward`` on the library path (bf16 / fp16).
 """
 import torch
 

@@ -412,6 +412,43 @@ def test_graphed_forward_replays_the_model():
         assert next(graphed.parameters()).is_cuda
 
 
+def test_graphed_pointrend_replays_survive_other_launches():
+    """Regression for the GPU memory fault of round 3: a captured PointRend forward must give
+    bit-identical replays however many unrelated kernels run between them.  A `hipMemsetAsync` inside the captured step
+    (a memset node) broke exactly this -- wrong point indices after ~2 000 launches, a memory fault a few thousand
+    later -- so everything capturable zeroes with kernels.  4 images (multi-image top-k), two shapes, 20 000 launches."""
+    from empanada_amd import _hip
+    from empanada_amd.models import GraphedForward, PanopticDeepLabPR, prepare_for_inference, synthesize_weights
+    mito = dict(encoder='resnet50', num_classes=1, stage4_stride=16, decoder_channels=256, low_level_stages=[1],
+                low_level_channels_project=[32], atrous_rates=[2, 4, 6], aspp_channels=None, aspp_dropout=0.5,
+                ins_decoder=True, ins_ratio=0.5)
+    torch.manual_seed(5)
+    m = synthesize_weights(PanopticDeepLabPR(**mito)).eval()
+    with torch.no_grad():
+        for head in (m.semantic_head, m.ins_center, m.ins_xy):
+            head.head[1].weight.mul_(1e-3)
+        net = prepare_for_inference(m, 'cuda')
+        x = torch.randn(4, 1, 256, 256, device='cuda').contiguous(memory_format=torch.channels_last)
+        eager = {k: v.clone() for k, v in net(x, 2, False).items()}
+        graphed = GraphedForward(net, clone_outputs=False)
+        first = {k: v.clone() for k, v in graphed(x, 2, False).items()}
+        for k in eager:
+            assert first[k].shape == eager[k].shape
+        bad = (first['sem_logits'] - eager['sem_logits']).abs() > 1e-4 * eager['sem_logits'].abs().max() + 1e-5
+        assert bad.float().mean().item() < 2e-3                     # (eager vs graph: MIOpen's batch-dependent kernels)
+        xs = torch.randn(1, 32, 4, 4, device='cuda').contiguous(memory_format=torch.channels_last)
+        ws = torch.randn(32, 1, 1, 32, device='cuda')
+        t = torch.zeros(64, device='cuda')
+        for rnd in range(2):
+            for _ in range(5000):
+                _hip.conv_bn_act_nhwc(xs, ws)
+                t.add_(1.0)
+            net(x, 2, False)                                         # and an eager forward of the same model
+            again = graphed(x, 2, False)
+            for k in first:
+                assert torch.equal(again[k], first[k]), (rnd, k, int((again[k] != first[k]).sum()))
+
+
 @pytest.mark.parametrize('force', ['direct', 'wino4'])
 def test_model_forward_large_batch_equals_small_batches(force):
     """128 slices of 512^2 in one model call (activations of 2^29 elements = 2 GiB and more: 32-bit byte offsets
