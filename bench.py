@@ -131,6 +131,10 @@ def parse():
     ap.add_argument('--out', default=None, help='zarr v2 directory the labelled volume is written to (default: a '
                     'scratch store under /dev/shm)')
     ap.add_argument('--keep-out', action='store_true', help='do not delete the output store at the end')
+    ap.add_argument('--tile', type=int, default=0,
+                    help='stack mode: cut every slice into overlapping tiles of this size (BASELINE configs[4]: "tiled '
+                         'overlap stitching"): forward per tile, per-tile post-processing, tile merge on device tables')
+    ap.add_argument('--tile-overlap', type=int, default=128)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel of the forward from Python (no HIP graph)')
     args = ap.parse_args()
     if args.steps is None:
@@ -186,6 +190,7 @@ class Pipeline:
         self.dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[args.dtype]
         self.model = prepare_for_inference(build_model(args.model), device, self.dtype)
         self.model_args = MODEL_ARGS.get(args.model, ())
+        self.tiler = None
         self.device = device
         self.batch = args.batch
         self.tune_batch = args.tune_batch
@@ -302,12 +307,54 @@ class Pipeline:
                     + dst.sum(dtype=torch.float64))          # per call: the fp64 temporary stays one batch large
         return prob, chk
 
+    @torch.no_grad()
+    def forward_tiled(self, dv, tiler):
+        """stack mode with --tile: the model runs on every tile's crop of every slice (inference/tile.py:170-194) --
+        (tile area x tiles) / plane area times the pixels of an untiled pass.  Returns the checksum over all tiles."""
+        from empanada_amd import _hip
+        model = self.model
+        if self.dense_profile_left > 0:
+            self.dense_profile_left -= 1
+            _hip.PROFILE_SKIP.difference_update(DENSE_KERNELS)
+        else:
+            _hip.PROFILE_SKIP.update(DENSE_KERNELS)
+            if self.graphed is not None and self.graphs_enabled and self.dtype == torch.float32:
+                model = self.graphed
+        chk = torch.zeros((), dtype=torch.float64, device=self.device)
+        n = dv.n_slices('xy')
+        th, tw = tiler.yranges[0][1] - tiler.yranges[0][0], tiler.xranges[0][1] - tiler.xranges[0][0]
+        per = self.slices_per_call(th, tw)
+        for s in range(0, n, per):
+            x = dv.batch('xy', s, min(n, s + per))
+            for (y0, y1), (x0, x1) in zip(tiler.yranges, tiler.xranges):
+                xt = x[:, :, y0:y1, x0:x1].contiguous(memory_format=torch.channels_last)
+                out = model(xt, *self.model_args)
+                prob = _hip.logits_to_prob(out['sem_logits'].float().contiguous())
+                chk += (out['ctr_hmp'].float().sum(dtype=torch.float64) + out['offsets'].float().sum(dtype=torch.float64)
+                        + prob.sum(dtype=torch.float64))
+        return None, chk
+
+    def panoptic(self, heads, tiler=None):
+        """planted heads of a stack -> panoptic labels (D, H, W): the whole-plane kernels, or per tile + the tile merge
+        (inference/tiled.py; one-run objects, on which the reference's merge raises, are kept)"""
+        from empanada_amd.inference import sharded, tiled
+        if tiler is None:
+            return sharded.sharded_panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'],
+                                                  coarse_boundaries=COARSE, **ENGINE)
+
+        def crop(i):
+            (y0, y1), (x0, x1) = tiler.yranges[i], tiler.xranges[i]
+            return {k: v[:, :, y0:y1, x0:x1].contiguous() for k, v in heads.items()}
+        kw = {k: v for k, v in ENGINE.items() if k not in ('thing_list', 'label_divisor')}
+        return tiled.tiled_panoptic_stack(crop, heads['sem'].shape[0], tiler, LABELS, thing_list=ENGINE['thing_list'],
+                                          label_divisor=ENGINE['label_divisor'], coarse_boundaries=COARSE,
+                                          on_single_run='keep', **kw)
+
     def postprocess(self, heads, out_host):
         """stack mode: probabilities -> labelled slab in pinned host memory.  Same code path for 1 and N ranks
         (empanada_amd/inference/sharded.py); with one rank the collectives are no-ops."""
         from empanada_amd.inference import sharded
-        pan = sharded.sharded_panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'],
-                                             coarse_boundaries=COARSE, **ENGINE)
+        pan = self.panoptic(heads, self.tiler)
         vol = sharded.sharded_stack_volume(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'],
                                            min_size=FILTERS['min_size'], min_span=FILTERS['min_span'], **MATCH)
         out_host.copy_(vol.view(torch.int32), non_blocking=True)
@@ -736,12 +783,15 @@ def roofline_block(prof, vox_launch, thing_frac, steps, dense_passes):
 
 
 # ----------------------------------------------------------------------------------------------- stack mode
-def cpu_baseline_stack(args, vol_u8, heads, n_slices):
+def cpu_baseline_stack(args, vol_u8, heads, n_slices, pipe=None):
     """The oracle chain (CPU restatement of the reference) + torch-CPU forward on a bounded sample of the
-    same workload: the first n_slices slices.  kind = 'port'."""
+    same workload: the first n_slices slices.  kind = 'port'.  With --tile the forward runs on every tile's crop and the
+    panoptic slices come from the reference's tiled sequence (oracle/pipeline.py::tiled_plane_pans)."""
+    from oracle import pipeline as PL
     from oracle import postprocess as OP
     from oracle import rle_ops as OR
     from oracle import rle_seg as OS
+    tiler = pipe.tiler if pipe is not None else None
     n = min(n_slices, vol_u8.shape[0])
     cores = min(16, os.cpu_count() or 1)          # the GPU box grants a 16-core share per GPU
     torch.set_num_threads(cores)
@@ -750,14 +800,22 @@ def cpu_baseline_stack(args, vol_u8, heads, n_slices):
     x = (x - 255 * NORM['mean']) / (255 * NORM['std'])
     sem, ctr, off = (heads[k][:n].cpu().numpy() for k in ('sem', 'ctr_hmp', 'offsets'))
     t0 = time.perf_counter()
+    crops = [(slice(None), slice(None))] if tiler is None else [(slice(*yr), slice(*xr)) for yr, xr in
+                                                                  zip(tiler.yranges, tiler.xranges)]
     with torch.no_grad():
         for i in range(n):
-            out = model(x[i:i + 1], *MODEL_ARGS.get(args.model, ()))
-            _ = torch.sigmoid(out['sem_logits']) if len(LABELS) == 1 else torch.softmax(out['sem_logits'], dim=1)
+            for ys, xs in crops:
+                out = model(x[i:i + 1, :, ys, xs], *MODEL_ARGS.get(args.model, ()))
+                _ = torch.sigmoid(out['sem_logits']) if len(LABELS) == 1 else torch.softmax(out['sem_logits'], dim=1)
     t_conv = time.perf_counter() - t0
-    pans = OP.engine3d_stack([sem[t:t + 1] for t in range(n)], [ctr[t:t + 1] for t in range(n)],
-                             [off[t:t + 1] for t in range(n)], coarse_boundaries=COARSE, render=True, **ENGINE)
-    pans = [p.squeeze() for p in pans]
+    if tiler is None:
+        pans = OP.engine3d_stack([sem[t:t + 1] for t in range(n)], [ctr[t:t + 1] for t in range(n)],
+                                 [off[t:t + 1] for t in range(n)], coarse_boundaries=COARSE, render=True, **ENGINE)
+        pans = [p.squeeze() for p in pans]
+    else:
+        pans = PL.tiled_plane_pans(sem, ctr, off, dict(ENGINE, coarse_boundaries=COARSE), tiler.yranges, tiler.xranges,
+                                   tiler.overlap_rle, labels=LABELS, single_run='keep')
+        pans = [p.astype(np.int64) for p in pans]
     matchers = OS.create_matchers(ENGINE['thing_list'], ENGINE['label_divisor'], MATCH['merge_iou_thr'],
                                   MATCH['merge_ioa_thr'])
     stack = OS.forward_matching(pans, matchers, LABELS, ENGINE['label_divisor'], ENGINE['thing_list'])
@@ -778,7 +836,8 @@ def cpu_baseline_stack(args, vol_u8, heads, n_slices):
     from empanada_amd.evaluation import volume_pq
     from empanada_amd.inference import sharded
     sub = {k: heads[k][:n].contiguous() for k in heads}
-    pan = sharded.sharded_panoptic_stack(sub['sem'], sub['ctr_hmp'], sub['offsets'], coarse_boundaries=COARSE, **ENGINE)
+    pan = pipe.panoptic(sub, tiler) if pipe is not None else sharded.sharded_panoptic_stack(
+        sub['sem'], sub['ctr_hmp'], sub['offsets'], coarse_boundaries=COARSE, **ENGINE)
     got = sharded.sharded_stack_volume(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'],
                                        min_size=FILTERS['min_size'], min_span=FILTERS['min_span'], **MATCH)
     got = got.view(torch.int32).cpu().numpy().astype(np.uint32)
@@ -799,8 +858,13 @@ def main_stack(args, device, rank, world):
     vol, heads, n_obj = build_inputs(D, S, device, seed_offset=rank, things=args.things)
     log(f'inputs ready ({n_obj} planted objects); building model')
     pipe = Pipeline(args, device)
+    if args.tile:
+        from empanada_amd.inference.tile import Tiler
+        pipe.tiler = Tiler((S, S), args.tile, args.tile_overlap)
+        log(f'{len(pipe.tiler)} tiles of {args.tile} px, overlap >= {args.tile_overlap}')
+    fwd = (lambda v: pipe.forward_tiled(v, pipe.tiler)) if args.tile else pipe.forward
     if not args.no_tune:
-        pipe.tune(S, args.save_tune, args.load_tune)
+        pipe.tune(args.tile or S, args.save_tune, args.load_tune)
     host_out = torch.empty((D, S, S), dtype=torch.int32).pin_memory()
 
     def barrier():
@@ -811,7 +875,7 @@ def main_stack(args, device, rank, world):
 
     for i in range(args.warmup):
         t_w = time.perf_counter()
-        prob, chk = pipe.forward(vol)
+        prob, chk = fwd(vol)
         out = pipe.postprocess(heads, host_out)
         torch.cuda.synchronize()
         log(f'warmup {i}: total {time.perf_counter() - t_w:.2f}s')
@@ -824,7 +888,7 @@ def main_stack(args, device, rank, world):
     if args.no_pipeline:
         for k in range(args.steps):
             ev[3 * k].record()
-            prob, chk = pipe.forward(vol)
+            prob, chk = fwd(vol)
             chks.append(chk)
             ev[3 * k + 1].record()
             out = pipe.postprocess(heads, host_out)
@@ -841,8 +905,7 @@ def main_stack(args, device, rank, world):
         def downstream(k):
             with torch.cuda.stream(post):
                 post.wait_event(fwd_done[k])
-                pan = sharded.sharded_panoptic_stack(heads['sem'], heads['ctr_hmp'], heads['offsets'],
-                                                     coarse_boundaries=COARSE, **ENGINE)
+                pan = pipe.panoptic(heads, pipe.tiler)
                 table, host = sharded.sharded_tables(pan, LABELS, ENGINE['thing_list'], ENGINE['label_divisor'])
                 tc = time.perf_counter()
                 final = sharded.gather_tables_and_chain(host, pan.shape[0], LABELS, ENGINE['thing_list'],
@@ -857,7 +920,7 @@ def main_stack(args, device, rank, world):
         for k in range(args.steps + 1):
             if k < args.steps:
                 ev[3 * k].record()
-                prob, chk = pipe.forward(vol)                      # asynchronous: only enqueues
+                prob, chk = fwd(vol)                               # asynchronous: only enqueues
                 chks.append(chk)
                 ev[3 * k + 1].record()
                 fwd_done[k].record()
@@ -885,7 +948,9 @@ def main_stack(args, device, rank, world):
         thing_frac = float((heads['sem'].argmax(dim=1) > 0).float().mean().item())
     roof, per_call, per_pass = roofline_block(prof, float(D) * S * S, thing_frac, args.steps,
                                               dense_passes=1 if not args.no_pipeline else args.steps)
-    flops = FLOPS_PER_VOXEL.get(args.model, 0.0) * D * S * S
+    tile_px = sum((y1 - y0) * (x1 - x0) for (y0, y1), (x0, x1) in zip(pipe.tiler.yranges, pipe.tiler.xranges)) \
+        if args.tile else S * S                       # pixels the model sees per slice
+    flops = FLOPS_PER_VOXEL.get(args.model, 0.0) * D * tile_px
     res = {
         'metric': 'Mvox/s end-to-end 3D panoptic inference, xy stack only (no consensus); PQ vs CPU ref',
         'value': round(vox_total / dt / 1e6, 3), 'unit': 'Mvox/s', 'n_gpus': world, 'steps': args.steps,
@@ -893,7 +958,10 @@ def main_stack(args, device, rank, world):
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else args.dtype,
         'data': 'synthetic',
         'config': {'workload': f'stack (xy) inference, {D * world}x{S}x{S} uint8 volume (an independent {D}-slice '
-                               f'volume per rank), {MODELS[args.model]} '
+                               f'volume per rank), '
+                               + (f'every slice cut into {len(pipe.tiler)} overlapping tiles of {args.tile} px (overlap >= '
+                                  f'{args.tile_overlap}): forward and post-processing per tile, tile merge on device '
+                                  f'tables, ' if args.tile else '') + f'{MODELS[args.model]} '
                                f'C={1 if len(LABELS) == 1 else len(LABELS) + 1} fp-forward on every slice + HIP '
                                f'post-processing on planted heads (ks=7, {"1/4-res instance" if COARSE else "full-res"} heads), {n_obj} planted objects per rank',
                    'mode': 'stack', 'slices_per_rank': D, 'batch': pipe.slices_per_call(S, S),
@@ -910,7 +978,7 @@ def main_stack(args, device, rank, world):
         res['forward_check'] = forward_check(args, pipe, vol, axes=('xy',))
     if not args.no_cpu_baseline and world == 1 and args.cpu_slices > 0:
         log('cpu baseline')
-        res['cpu_baseline'] = cpu_baseline_stack(args, vol.vol, heads, args.cpu_slices)
+        res['cpu_baseline'] = cpu_baseline_stack(args, vol.vol, heads, args.cpu_slices, pipe)
     else:
         res['cpu_baseline'] = None
     print(json.dumps(res), flush=True)

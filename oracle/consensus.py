@@ -193,7 +193,17 @@ def merge_objects_from_trackers(object_trackers, pixel_vote_thr=2, cluster_iou_t
     return instances
 
 
-def merge_semantic_from_tiles(tiles):
+def _join(list_of_ranges, single_run):
+    """join_ranges (array_utils.py:665-671), which raises UnboundLocalError on ONE range in total (:659-661) -- the
+    reference's behaviour, `single_run='raise'`; 'keep' returns that range (the volume drivers' choice, documented in
+    empanada_amd/inference/tiled.py)"""
+    from .rle_ops import join_ranges
+    if single_run == 'keep' and sum(len(r) for r in list_of_ranges) == 1:
+        return np.concatenate(list_of_ranges).reshape(1, 2)
+    return join_ranges(list_of_ranges)
+
+
+def merge_semantic_from_tiles(tiles, single_run='raise'):
     """consensus.py:471-524"""
     from .rle_ops import join_ranges
     label_id, boxes, rngs = None, [], []
@@ -209,11 +219,11 @@ def merge_semantic_from_tiles(tiles):
     box = boxes[0]
     for b in boxes[1:]:
         box = merge_boxes(box, b)
-    r = join_ranges(rngs)
+    r = _join(rngs, single_run)
     return {label_id: {'box': box, 'starts': r[:, 0], 'runs': r[:, 1] - r[:, 0]}}
 
 
-def merge_objects_from_tiles(tiles, overlap_rle=None):
+def merge_objects_from_tiles(tiles, overlap_rle=None, single_run='raise'):
     """consensus.py:526-625"""
     from .rle_ops import join_ranges, ranges_to_rle, rle_ioa
     tile_idx, labels, boxes, starts, runs = [], [], [], [], []
@@ -235,8 +245,8 @@ def merge_objects_from_tiles(tiles, overlap_rle=None):
         box = graph.nodes[cluster[0]]['box']
         for nid in cluster[1:]:
             box = merge_boxes(box, graph.nodes[nid]['box'])
-        voted = join_ranges([np.stack([graph.nodes[n]['starts'], graph.nodes[n]['starts'] + graph.nodes[n]['runs']],
-                                      axis=1) for n in cluster])
+        voted = _join([np.stack([graph.nodes[n]['starts'], graph.nodes[n]['starts'] + graph.nodes[n]['runs']],
+                                axis=1) for n in cluster], single_run)
         if overlap_rle is not None and len(cluster) < 2 and np.any(voted):
             rle = ranges_to_rle(voted)
             if rle_ioa(np.asarray(overlap_rle[0]), np.asarray(overlap_rle[1]), rle[:, 0], rle[:, 1]) > 0.1:

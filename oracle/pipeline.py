@@ -150,6 +150,41 @@ def _run_workers(d, kind, jobs, workers):
     return out
 
 
+def tiled_plane_pans(sem, ctr, off, engine, yranges, xranges, overlap_rle, *, labels, single_run='raise', workers=1):
+    """The reference's tiled sequence (tests/test_tiling.py:26-47) over a stack: every tile's crop of the heads through
+    the 3d engine (the recursive median runs along z inside each tile position) -> pan_seg_to_rle_seg(force_connected
+    = False) -> Tiler.translate_rle_seg (inference/tile.py:122-168) -> merge_objects_from_tiles with the overlap test /
+    merge_semantic_from_tiles per class (consensus.py:471-625) -> painted panoptic image of the whole plane, per slice.
+    yranges / xranges / overlap_rle: the tiler's.  Returns the list of (H, W) uint32 images."""
+    H, W = sem.shape[-2:]
+    kw = dict(engine)
+    things, div = kw['thing_list'], kw['label_divisor']
+    per_tile = []
+    for (y0, y1), (x0, x1) in zip(yranges, xranges):
+        pans, _ = plane_pans(np.ascontiguousarray(sem[..., y0:y1, x0:x1]), np.ascontiguousarray(ctr[..., y0:y1, x0:x1]),
+                             np.ascontiguousarray(off[..., y0:y1, x0:x1]), kw, labels=labels, workers=workers,
+                             with_rle=False)
+        per_tile.append([OS.pan_seg_to_rle_seg(p, labels, div, things, force_connected=False) for p in pans])
+    out = []
+    for z in range(len(per_tile[0])):
+        img = np.zeros((H, W), dtype=np.uint32)
+        for l in labels:
+            moved = []
+            for i, ((y0, y1), (x0, x1)) in enumerate(zip(yranges, xranges)):
+                w = x1 - x0
+                insts = {}
+                for k, a in per_tile[i][z][l].items():
+                    b = a['box']
+                    insts[k] = {'box': (b[0] + y0, b[1] + x0, b[2] + y0, b[3] + x0), 'runs': a['runs'],
+                                'starts': np.ravel_multi_index((a['starts'] // w + y0, a['starts'] % w + x0), (H, W))}
+                moved.append(insts)
+            merged = OC.merge_objects_from_tiles(moved, overlap_rle, single_run) if l in things else \
+                OC.merge_semantic_from_tiles(moved, single_run)
+            OR.numpy_fill_instances(img.reshape(-1), merged)
+        out.append(img)
+    return out
+
+
 def plane_trackers(rle_segs, axis, shape3d, labels, thing_list, div, match, filters=None):
     """patterns.py:68-121 + tracker.py: per-slice rle_segs -> forward matching -> backward matching -> trackers
     (-> size / span filters).  `rle_segs` is consumed (matched in place like the reference's rle_stack)."""
