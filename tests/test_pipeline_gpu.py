@@ -429,13 +429,19 @@ def test_graphed_pointrend_replays_survive_other_launches():
             head.head[1].weight.mul_(1e-3)
         net = prepare_for_inference(m, 'cuda')
         x = torch.randn(4, 1, 256, 256, device='cuda').contiguous(memory_format=torch.channels_last)
+        net(x, 2, False)
+        # every convolution on this package's (deterministic) kernels: at small batches MIOpen picks split-K kernels
+        # that accumulate with atomics, and a last-bit difference upstream reshuffles PointRend's top-k
+        from empanada_amd.models.panoptic_deeplab import FusedConvBNAct
+        for mod in net.modules():
+            if isinstance(mod, FusedConvBNAct) and mod._seen is not None:
+                assert 'direct' in mod.candidates(mod._seen[1])
+                mod.impl = 'direct'
         eager = {k: v.clone() for k, v in net(x, 2, False).items()}
         graphed = GraphedForward(net, clone_outputs=False)
         first = {k: v.clone() for k, v in graphed(x, 2, False).items()}
         for k in eager:
-            assert first[k].shape == eager[k].shape
-        bad = (first['sem_logits'] - eager['sem_logits']).abs() > 1e-4 * eager['sem_logits'].abs().max() + 1e-5
-        assert bad.float().mean().item() < 2e-3                     # (eager vs graph: MIOpen's batch-dependent kernels)
+            assert torch.equal(first[k], eager[k]), k
         xs = torch.randn(1, 32, 4, 4, device='cuda').contiguous(memory_format=torch.channels_last)
         ws = torch.randn(32, 1, 1, 32, device='cuda')
         t = torch.zeros(64, device='cuda')

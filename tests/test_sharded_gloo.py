@@ -374,3 +374,40 @@ def test_chain_with_native_lsap_equals_chain_with_scipy(seed):
     b, fb = chain_from_tables(host, pan.shape[0], [1, 2], [1], DIV, 0.25, 0.25, lsap='scipy')
     np.testing.assert_array_equal(a, b)
     assert {k: list(v.items()) for k, v in fa.items()} == {k: list(v.items()) for k, v in fb.items()}
+
+
+def _worker_inputs(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import bench
+        em, lab, cls = bench.shared_host_inputs((20, 24, 28), rank, 1)
+        q.put((rank, em.sum(dtype=np.int64), lab.astype(np.int64).sum(), len(cls), em.flags.writeable))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_inputs_are_drawn_once_per_node():
+    """bench.shared_host_inputs (N-rank runs): rank 0 draws the synthetic EM and label volumes into /dev/shm, the other
+    ranks map them -- every rank ends up with private copies of exactly the arrays a single rank draws, and the scratch
+    directory is gone afterwards."""
+    import bench
+    from empanada_amd import synthetic as SY
+    shape = (20, 24, 28)
+    lab, cls = SY.planted_labels(shape, fill=0.08, rmin=6, rmax=24, seed=4321, n_classes=1)
+    em = SY.em_volume(shape, seed=1234)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_inputs, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict((r, rest) for r, *rest in (q.get(timeout=180) for _ in range(3)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(3):
+        assert got[r][0] == em.sum(dtype=np.int64) and got[r][1] == lab.astype(np.int64).sum() and got[r][2] == len(cls)
+    base = '/dev/shm' if os.path.isdir('/dev/shm') else __import__('tempfile').gettempdir()
+    assert not os.path.exists(os.path.join(base, f'emp_bench_inputs_{port}'))
