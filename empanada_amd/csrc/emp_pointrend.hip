@@ -371,7 +371,8 @@ __global__ __launch_bounds__(256) void pr_scatter_kernel(const float *__restrict
         const int c = (int)(i % C);
         const int64_t p = i / C;
         const int n = (int)(p / k);
-        logits[((int64_t)n * C + c) * HW + idx[p]] = pts[p * ldp + c];
+        const int64_t id = idx[p];
+        if (id >= 0 && id < HW) logits[((int64_t)n * C + c) * HW + id] = pts[p * ldp + c];    // (a bad index writes nothing)
     }
 }
 
