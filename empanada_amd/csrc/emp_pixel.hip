@@ -402,13 +402,15 @@ extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr
 // contract (see emp_hip.h):
 //   s = fmaf(dx, dx, fl(dy*dy)); d = sqrt_rn(s); first strictly smaller d wins.
 // sqrt is monotone, so the comparison runs on s and d is only evaluated for near ties.
-// (A per-block pruning of the centre list by the bounding box of the voted locations was tried and removed: a tile
-// is two image rows, its box spans the slice and prunes nothing; the kernel is 0.2 % of a pass.)
+// Per WAVE (64 consecutive voted pixels = one or two objects) the centre list is pruned by the bounding box of the voted
+// locations before the exact vote (see phase 2): ~200 candidates per pixel at 1024^2 become a handful.
 // Work compaction: a block owns GP_TILE consecutive pixels.  Pixels that need a vote (all of them without a
 // semantic map, only thing pixels with one -- ~10 % of an EM slice) are compacted into an LDS list so that the
 // K-centre loop runs with full lanes; ids are staged in LDS and written back as one coalesced 16-byte store
 // per lane.  Traffic: 1 B (class) + 8 B (offsets, voted pixels only) read, 2 B written per pixel.
 #define GP_BATCH 8
+#define GP_CAND 248                // per-wave candidate list (entries); more survivors -> full scan
+#define GP_PRUNE_MIN 16            // slices with at most this many centres are scanned in full
 #define GP_THREADS 128
 #define GP_TILE 1024
 #define GP_PER_THREAD (GP_TILE / GP_THREADS)
@@ -503,14 +505,71 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
         if ((wantbits >> j) & 1u) todo[slot++] = (uint16_t)(l0 + j);
     __syncthreads();
 
-    // phase 2: nearest-centre vote over the compacted list
+    // phase 2: nearest-centre vote over the compacted list, one wave = 64 consecutive voted pixels at a time.
+    // Those 64 pixels belong to one or two objects of one or two image rows, so the locations they vote for
+    // (pixel + offset) fall into a small box around one or two centres.  Per wave (K > GP_PRUNE_MIN): the box of the
+    // wave's locations; U = the smallest over all centres of the LARGEST distance to the box (that centre is within U
+    // of every location); a centre whose SMALLEST distance to the box exceeds U -- by a relative 2e-4 in the squared
+    // distance, three orders of magnitude more than any rounding or root tie -- can be the nearest of no pixel of the
+    // wave and cannot tie with one.  The survivors (typically 1-4 of ~200 at 1024^2) keep their index order in a
+    // per-wave LDS list, and the exact vote below runs over them only.  Locations with NaN / inf widen the box to
+    // "keep everything"; a list that overflows falls back to the full scan.  (Round 2 tried this per BLOCK -- two
+    // image rows, a box spanning the slice -- and pruned nothing.)
+    __shared__ uint16_t cand[GP_THREADS / 64][GP_CAND + GP_BATCH];
     const int n = n_todo;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int l = todo[i];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int base = wave * 64; base < n; base += GP_THREADS) {           // wave-uniform trip count
+        const int i = base + lane;
+        const bool act = i < n;
+        const int l = act ? todo[i] : 0;
         const int64_t p = tile0 + l;
         const int y = (int)(p / w), x = (int)(p % w);
-        const float ly = __fadd_rn((float)(y * step), offy[p]);  // coord + offsets
-        const float lx = __fadd_rn((float)(x * step), offx[p]);
+        const float ly = act ? __fadd_rn((float)(y * step), offy[p]) : 0.f;  // coord + offsets
+        const float lx = act ? __fadd_rn((float)(x * step), offx[p]) : 0.f;
+        // candidate list of this wave-step: all centres 0..K-1, or the survivors of the box test
+        int n_cand = -1;                                                  // -1: scan all K centres
+        if (K > GP_PRUNE_MIN) {
+            float ymin = act ? ly : INFINITY, ymax = act ? ly : -INFINITY;
+            float xmin = act ? lx : INFINITY, xmax = act ? lx : -INFINITY;
+            bool wild = act && !(fabsf(ly) < 3e38f && fabsf(lx) < 3e38f);  // NaN / inf location in this lane
+#pragma unroll
+            for (int o = 32; o; o >>= 1) {
+                ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+                xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+            }
+            if (!__ballot(wild)) {
+                float u2 = INFINITY;
+                for (int k = lane; k < K; k += 64) {
+                    const float2 c = ctr[k];
+                    const float dyh = fmaxf(fabsf(c.x - ymin), fabsf(c.x - ymax));
+                    const float dxh = fmaxf(fabsf(c.y - xmin), fabsf(c.y - xmax));
+                    u2 = fminf(u2, dyh * dyh + dxh * dxh);
+                }
+#pragma unroll
+                for (int o = 32; o; o >>= 1) u2 = fminf(u2, __shfl_xor(u2, o));
+                u2 *= 1.0001f;
+                int cnt = 0;
+                for (int k0 = 0; k0 < K; k0 += 64) {
+                    const int k = k0 + lane;
+                    bool keep = false;
+                    if (k < K) {
+                        const float2 c = ctr[k];
+                        const float dyl = fmaxf(fmaxf(ymin - c.x, c.x - ymax), 0.f);
+                        const float dxl = fmaxf(fmaxf(xmin - c.y, c.y - xmax), 0.f);
+                        keep = (dyl * dyl + dxl * dxl) * 0.9999f <= u2;
+                    }
+                    const uint64_t m = __ballot(keep);
+                    const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                    if (keep && pos < GP_CAND) cand[wave][pos] = (uint16_t)k;
+                    cnt += __popcll(m);
+                }
+                if (cnt <= GP_CAND) {
+                    if (lane < GP_BATCH) cand[wave][cnt + lane] = (uint16_t)K;      // padding: centre K is +inf
+                    n_cand = cnt;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         // First index with the strictly smallest d = sqrt_rn(s).  sqrt_rn is monotone, and two floats whose ratio
         // exceeds 1 + 2^-21 cannot round to the same square root, so the comparison of d reduces to a comparison
         // of s except in a narrow near-tie band, where both roots are evaluated exactly.  sbest is the s of the
@@ -522,13 +581,15 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
         // Centres past K are padded with +inf (s = inf never wins).  Each batch is first run branch-free under the
         // assumption "a near tie does not win"; if any lane of the wave met a near tie (rare), the batch is redone
         // from the saved state with the exact comparison of the correctly rounded roots.
-        float2 c[GP_BATCH];
+        const int n_scan = n_cand < 0 ? K : n_cand;
+        for (int k0 = 0; k0 < n_scan; k0 += GP_BATCH) {
+            float2 c[GP_BATCH];
+            int cid[GP_BATCH];
 #pragma unroll
-        for (int j = 0; j < GP_BATCH; ++j) c[j] = ctr[j];
-        for (int k0 = 0; k0 < K; k0 += GP_BATCH) {
-            float2 cn[GP_BATCH];
-#pragma unroll
-            for (int j = 0; j < GP_BATCH; ++j) cn[j] = ctr[k0 + GP_BATCH + j];      // next batch (padded), in flight
+            for (int j = 0; j < GP_BATCH; ++j) {
+                cid[j] = n_cand < 0 ? k0 + j : (int)((volatile uint16_t *)cand[wave])[k0 + j];
+                c[j] = ctr[cid[j]];
+            }
             const float sbest0 = sbest, sclear0 = sclear;
             const int id0 = id;
             bool any_near = false;
@@ -542,7 +603,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
                 any_near = any_near || (lt && !better);
                 sbest = better ? s2 : sbest;
                 sclear = better ? __fmul_rn(s2, 0.99999904632568359375f) : sclear;
-                id = better ? k0 + j + 1 : id;
+                id = better ? cid[j] + 1 : id;
             }
             if (__ballot(any_near)) {
                 if (any_near) {
@@ -556,14 +617,13 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
                         bool better = lt && (s2 <= sclear || sqrt_rn_exact(s2) < sqrt_rn_exact(sbest));
                         sbest = better ? s2 : sbest;
                         sclear = better ? __fmul_rn(s2, 0.99999904632568359375f) : sclear;
-                        id = better ? k0 + j + 1 : id;
+                        id = better ? cid[j] + 1 : id;
                     }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < GP_BATCH; ++j) c[j] = cn[j];
         }
-        ids_tile[l] = (uint16_t)id;
+        if (act) ids_tile[l] = (uint16_t)id;
+        __builtin_amdgcn_wave_barrier();                                  // the next step rewrites this wave's list
     }
     __syncthreads();
 
