@@ -413,6 +413,8 @@ extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr
 #define GP_PRUNE_MIN 16            // slices with at most this many centres are scanned in full
 #define GP_THREADS 128
 #define GP_TILE 1024
+#define GP_TW 64                   // a block's patch: GP_TH rows x GP_TW columns = GP_TILE pixels
+#define GP_TH (GP_TILE / GP_TW)
 #define GP_PER_THREAD (GP_TILE / GP_THREADS)
 
 // correctly rounded fp32 square root: the double-precision root of a float rounds to the correctly rounded float
@@ -460,16 +462,21 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
     const float *offx = offy + hw;
     uint16_t *out = out_ids + (int64_t)d * hw;
     const uint8_t *sm = sem ? sem + (int64_t)d * hw : nullptr;
-    const int64_t tile0 = (int64_t)blockIdx.x * GP_TILE;
+    // a block owns a GP_TH x GP_TW patch of the slice (not GP_TILE consecutive pixels of a row): its voted pixels belong
+    // to one or two objects, which is what makes the per-wave pruning of phase 2 bite
+    const int tiles_x = (w + GP_TW - 1) / GP_TW;
+    const int ty0 = (int)(blockIdx.x / tiles_x) * GP_TH, tx0 = (int)(blockIdx.x % tiles_x) * GP_TW;
     const float sinit = (K > 20) ? 1e10f : INFINITY;   // sqrt_rn(1e10f) == 1e5f exactly
     const int idinit = (K > 20 || K == 0) ? 0 : 1;
 
     // phase 1: which pixels of the tile are voted on
-    const int l0 = threadIdx.x * GP_PER_THREAD;
+    const int l0 = threadIdx.x * GP_PER_THREAD;        // local index l = row * GP_TW + column inside the patch
+    const int y_t = ty0 + l0 / GP_TW, x_t = tx0 + l0 % GP_TW;          // the thread's GP_PER_THREAD pixels: one row
+    const int64_t p0 = (int64_t)y_t * w + x_t;
+    const bool row_ok = y_t < h;
     unsigned wantbits = 0;
     {
-        const int64_t p0 = tile0 + l0;
-        if (sm && p0 + GP_PER_THREAD <= hw && ((reinterpret_cast<uintptr_t>(sm + p0) & 7) == 0)) {
+        if (sm && row_ok && x_t + GP_PER_THREAD <= w && ((reinterpret_cast<uintptr_t>(sm + p0) & 7) == 0)) {
             uint2 c8 = *reinterpret_cast<const uint2 *>(sm + p0);
             unsigned long long bytes = ((unsigned long long)c8.y << 32) | c8.x;
 #pragma unroll
@@ -477,10 +484,8 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
                 if ((thing_mask >> ((bytes >> (8 * j)) & 0xff)) & 1u) wantbits |= 1u << j;
         } else {
 #pragma unroll
-            for (int j = 0; j < GP_PER_THREAD; ++j) {
-                int64_t p = p0 + j;
-                if (p < hw && (!sm || ((thing_mask >> sm[p]) & 1u))) wantbits |= 1u << j;
-            }
+            for (int j = 0; j < GP_PER_THREAD; ++j)
+                if (row_ok && x_t + j < w && (!sm || ((thing_mask >> sm[p0 + j]) & 1u))) wantbits |= 1u << j;
         }
     }
     if (K == 0) wantbits = 0;
@@ -522,8 +527,8 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
         const int i = base + lane;
         const bool act = i < n;
         const int l = act ? todo[i] : 0;
-        const int64_t p = tile0 + l;
-        const int y = (int)(p / w), x = (int)(p % w);
+        const int y = ty0 + l / GP_TW, x = tx0 + l % GP_TW;
+        const int64_t p = (int64_t)y * w + x;
         const float ly = act ? __fadd_rn((float)(y * step), offy[p]) : 0.f;  // coord + offsets
         const float lx = act ? __fadd_rn((float)(x * step), offx[p]) : 0.f;
         // candidate list of this wave-step: all centres 0..K-1, or the survivors of the box test
@@ -627,15 +632,14 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
     }
     __syncthreads();
 
-    // phase 3: coalesced write-back (8 ids = 16 bytes per lane)
-    {
-        const int64_t p0 = tile0 + l0;
-        if (p0 + GP_PER_THREAD <= hw && ((reinterpret_cast<uintptr_t>(out + p0) & 15) == 0)) {
+    // phase 3: write-back (8 ids = 16 bytes per lane, 128-byte row segments)
+    if (row_ok) {
+        if (x_t + GP_PER_THREAD <= w && ((reinterpret_cast<uintptr_t>(out + p0) & 15) == 0)) {
             *reinterpret_cast<uint4 *>(out + p0) = *reinterpret_cast<const uint4 *>(&ids_tile[l0]);
         } else {
 #pragma unroll
             for (int j = 0; j < GP_PER_THREAD; ++j)
-                if (p0 + j < hw) out[p0 + j] = ids_tile[l0 + j];
+                if (x_t + j < w) out[p0 + j] = ids_tile[l0 + j];
         }
     }
 }
@@ -653,8 +657,7 @@ extern "C" int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count
     EMP_REQUIRE(D >= 0 && D <= 65535 && h > 0 && w > 0, "group_pixels: bad shape");
     EMP_REQUIRE((int64_t)h * step < (1 << 24) && (int64_t)w * step < (1 << 24), "group_pixels: coords exceed fp32 integers");
     if (D == 0) return EMP_OK;
-    int64_t hw = (int64_t)h * w;
-    int gx = (int)emp_cdiv(hw, GP_TILE);
+    int gx = (int)(emp_cdiv(h, GP_TH) * emp_cdiv(w, GP_TW));
     float2 *ctr_f = reinterpret_cast<float2 *>(work);
     hipLaunchKernelGGL(group_centers_kernel, dim3(emp_grid((int64_t)D * (cap + 2 * GP_BATCH), 256, 1024)), dim3(256), 0,
                        emp_stream(stream), ctr_idx, ctr_count, cap, w, step, D, ctr_f);
