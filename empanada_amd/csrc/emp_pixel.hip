@@ -454,6 +454,8 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
     int K = ctr_count[d];
     if (K > cap) K = cap;
     const int64_t hw = (int64_t)h * w;
+    if (threadIdx.x == 0) n_todo = 0;
+    __syncthreads();
     // the slice's centres are read with a wave-uniform index: scalar loads, operands straight from SGPRs
     const float2 *__restrict__ ctr = ctr_f + (int64_t)d * (cap + 2 * GP_BATCH);
     const float *offy = offsets + (int64_t)d * 2 * hw;
@@ -463,16 +465,10 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
     // a block owns a GP_TH x GP_TW patch of the slice (not GP_TILE consecutive pixels of a row): its voted pixels belong
     // to one or two objects, which is what makes the per-wave pruning of phase 2 bite
     const int tiles_x = (w + GP_TW - 1) / GP_TW;
-    const int n_patches = tiles_x * ((h + GP_TH - 1) / GP_TH);
+    const int ty0 = (int)(blockIdx.x / tiles_x) * GP_TH, tx0 = (int)(blockIdx.x % tiles_x) * GP_TW;
     const float sinit = (K > 20) ? 1e10f : INFINITY;   // sqrt_rn(1e10f) == 1e5f exactly
     const int idinit = (K > 20 || K == 0) ? 0 : 1;
 
-    // a block walks over several patches (grid-stride): a million 128-thread blocks per 1024^3 plane cost more in
-    // block start-up than in work
-    for (int patch = blockIdx.x; patch < n_patches; patch += gridDim.x) {
-    const int ty0 = (patch / tiles_x) * GP_TH, tx0 = (patch % tiles_x) * GP_TW;
-    if (threadIdx.x == 0) n_todo = 0;
-    __syncthreads();
     // phase 1: which pixels of the tile are voted on
     const int l0 = threadIdx.x * GP_PER_THREAD;        // local index l = row * GP_TW + column inside the patch
     const int y_t = ty0 + l0 / GP_TW, x_t = tx0 + l0 % GP_TW;          // the thread's GP_PER_THREAD pixels: one row
@@ -646,8 +642,6 @@ __global__ __launch_bounds__(GP_THREADS) void group_pixels_kernel(const float2 *
                 if (x_t + j < w) out[p0 + j] = ids_tile[l0 + j];
         }
     }
-    __syncthreads();                                   // todo / ids_tile / cand are reused by the next patch
-    }
 }
 
 extern "C" int64_t emp_group_work_elems(int D, int cap) { return 2 * (int64_t)(D > 0 ? D : 1) * (cap + 2 * GP_BATCH); }
@@ -663,10 +657,7 @@ extern "C" int emp_group_pixels(const int32_t *ctr_idx, const int32_t *ctr_count
     EMP_REQUIRE(D >= 0 && D <= 65535 && h > 0 && w > 0, "group_pixels: bad shape");
     EMP_REQUIRE((int64_t)h * step < (1 << 24) && (int64_t)w * step < (1 << 24), "group_pixels: coords exceed fp32 integers");
     if (D == 0) return EMP_OK;
-    const int64_t n_patches = emp_cdiv(h, GP_TH) * emp_cdiv(w, GP_TW);
-    int per_block = (int)(n_patches * D / 131072);     // ~128 k blocks per launch at most, up to 8 patches per block
-    per_block = per_block < 1 ? 1 : per_block > 8 ? 8 : per_block;
-    int gx = (int)emp_cdiv(n_patches, per_block);
+    int gx = (int)(emp_cdiv(h, GP_TH) * emp_cdiv(w, GP_TW));
     float2 *ctr_f = reinterpret_cast<float2 *>(work);
     hipLaunchKernelGGL(group_centers_kernel, dim3(emp_grid((int64_t)D * (cap + 2 * GP_BATCH), 256, 1024)), dim3(256), 0,
                        emp_stream(stream), ctr_idx, ctr_count, cap, w, step, D, ctr_f);
