@@ -208,3 +208,12 @@ def test_orthoplane_512_cubed_properties_and_whole_volume_oracle(tmp_path):
     print('oracle 512^3:', {k: round(t, 1) for k, t in tm.items()})
     assert n_exp == n_found
     np.testing.assert_array_equal(got_vol, exp[1])
+
+
+@pytest.mark.skipif(not os.environ.get('EMP_VERIFY_FULL'), reason='BASELINE configs[3] at 1024^3 against the oracle: ~5 min of CPU '
+                    'work and ~80 GB of host memory; set EMP_VERIFY_FULL=1 (last result: profiles/r3_verify_ortho1024.json)')
+def test_whole_1024_cubed_volume_equals_oracle():
+    """the metric's own volume, every voxel: HIP consensus volume == oracle consensus volume, ids included"""
+    import verify_full_size
+    res = verify_full_size.run(1024)
+    assert res['volumes_identical_ids_included'] and res['hip_consensus_instances'] > 6000, res

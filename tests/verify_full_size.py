@@ -1,7 +1,9 @@
-"""ONE-OFF full-size parity run (BASELINE configs[3], the metric's volume): the whole 1024^3 orthoplane consensus volume
-of the HIP path against the CPU oracle (oracle/pipeline.py, per-pixel stages on the host cores), instance ids included.
-Too long for the test suite (several minutes of CPU work, ~80 GB of host memory); its verdict goes to profiles/.
-  python tools/verify_full_size.py [S] > profiles/r3_verify_ortho<S>.json"""
+"""Full-size parity run (BASELINE configs[3], the metric's volume): the whole 1024^3 orthoplane consensus volume of the
+HIP path against the CPU oracle (oracle/pipeline.py, per-pixel stages on the host cores), instance ids included.
+Too long for the default test suite (about five minutes of CPU work, ~80 GB of host memory): run by hand, its verdict
+goes to profiles/ --
+  python tests/verify_full_size.py [S] > profiles/r3_verify_ortho<S>.json
+-- or as a test: EMP_VERIFY_FULL=1 python -m pytest tests/test_full_size_gpu.py -m gpu -k whole_1024"""
 import json
 import os
 import sys
@@ -21,8 +23,7 @@ def log(msg):
 T0 = time.perf_counter()
 
 
-def main():
-    S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+def run(S=1024):
     from empanada_amd import _hip
     from oracle import consensus as OC
     from oracle import pipeline as PL
@@ -74,9 +75,11 @@ def main():
            'oracle_per_plane_s(pixels+rle, match+track)': timers,
            'what': 'planted heads of bench.py (seeds 1234 / 4321 / 99 + s), MitoNet engine parameters; HIP: '
                    'bench.postprocess_planes; oracle: oracle/pipeline.py plane by plane + oracle consensus + fill'}
-    print(json.dumps(res), flush=True)
     log('identical' if same else f'DIFFERENT in {n_diff} voxels')
-    sys.exit(0 if same else 1)
+    return res
 
 
-main()
+if __name__ == '__main__':
+    result = run(int(sys.argv[1]) if len(sys.argv) > 1 else 1024)
+    print(json.dumps(result), flush=True)
+    sys.exit(0 if result['volumes_identical_ids_included'] else 1)
