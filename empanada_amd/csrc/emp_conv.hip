@@ -936,7 +936,13 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restric
                                                           int64_t T, int H, int W, int C4, int dil, float4 *__restrict__ V)
 {
     const int64_t total = T * C4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // XCD-aware block order (the grid is a multiple of 8): consecutive hardware block ids go to different XCDs, each with
+    // its own L2, while consecutive TILE ROWS share two of their six patch rows.  Logical block lb = the (b >> 3)-th of
+    // XCD (b & 7)'s contiguous range, so that the rows a patch shares with the tile row above are still in the L2 of
+    // the XCD that fetched them (round 2 measured the input being read 1.6x: neighbouring tile rows sat on different XCDs).
+    const int64_t chunk = gridDim.x >> 3;
+    const int64_t lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    for (int64_t i = lb * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         const int64_t t = i / C4;
         const int n = tiles[3 * t], by = tiles[3 * t + 1], bx = tiles[3 * t + 2];
@@ -1020,8 +1026,9 @@ extern "C" int emp_wino4_input_transform(const float *x, int N, int H, int W, in
     EMP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && dil >= 1 && T >= 0, "wino4_input: bad shape");
     EMP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(V)) & 15) == 0, "wino4_input: alignment");
     if (T == 0) return EMP_OK;
-    hipLaunchKernelGGL(wino4_input_kernel, dim3(emp_grid(T * (C / 4), 256, 16384)), dim3(256), 0, emp_stream(stream), x,
-                       tiles, T, H, W, C / 4, dil, reinterpret_cast<float4 *>(V));
+    const int grid = (emp_grid(T * (C / 4), 256, 16384) + 7) / 8 * 8;           // a multiple of 8: see the block order
+    hipLaunchKernelGGL(wino4_input_kernel, dim3(grid), dim3(256), 0, emp_stream(stream), x, tiles, T, H, W, C / 4, dil,
+                       reinterpret_cast<float4 *>(V));
     EMP_CHECK_LAUNCH("emp_wino4_input_transform");
     return EMP_OK;
 }
