@@ -211,14 +211,33 @@ def median_harden_stack(prob, ks, thr, want_prob=False):
     return (sem, outp) if want_prob else sem
 
 
+def _expect(what, t, dtype=None, shape=None, numel=None):
+    """operand check before a launch: the kernels index by the sizes they are TOLD -- a tensor of another dtype,
+    shape or device would be read out of bounds on the GPU, which can take the whole node down"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HipError(f"{what}: expected a tensor on the GPU")
+    if dtype is not None and t.dtype not in (dtype if isinstance(dtype, tuple) else (dtype,)):
+        raise HipError(f"{what}: dtype {t.dtype}, expected {dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise HipError(f"{what}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if numel is not None and t.numel() != numel:
+        raise HipError(f"{what}: {t.numel()} elements, expected {numel}")
+    return t
+
+
 def median_step(slices, out=None):
     """median over a list of ks same-shape fp32 cuda tensors (engines.py:59-66)."""
     require_gpu()
     ks = len(slices)
+    if not 1 <= ks <= MAX_KS:
+        raise HipError(f"median over {ks} slices (1..{MAX_KS} supported)")
+    for i, s in enumerate(slices):
+        _expect(f"median_step: slice {i}", s, torch.float32, slices[0].shape)
     slices = [s.contiguous() for s in slices]
     n = slices[0].numel()
     if out is None:
         out = torch.empty_like(slices[0])
+    _expect("median_step: out", out, torch.float32, numel=n)
     arr = (_P * ks)(*[s.data_ptr() for s in slices])
     call('emp_median_step', arr, ks, n, _ptr(out), stream())
     return out
@@ -227,6 +246,7 @@ def median_step(slices, out=None):
 def find_centers(hmp, thr, k, cap=1024):
     """hmp (D,h,w) fp32 -> idx (D,cap) int32 raster-sorted, count (D) int32."""
     require_gpu()
+    _expect("find_centers: heat map", hmp, torch.float32)
     D, h, w = hmp.shape
     hmp = hmp.contiguous()
     idx = torch.empty((D, cap), dtype=torch.int32, device=hmp.device)
@@ -238,14 +258,22 @@ def find_centers(hmp, thr, k, cap=1024):
 def group_pixels(idx, cnt, offsets, step, sem=None, thing_list=()):
     """offsets (D,2,h,w) fp32 -> ids (D,h,w) uint16.  sem (D,h,w) u8 restricts the vote to thing pixels."""
     require_gpu()
-    D, _, h, w = offsets.shape
+    _expect("group_pixels: offsets", offsets, torch.float32)
+    D, two, h, w = offsets.shape
+    if two != 2:
+        raise HipError(f"group_pixels: offsets must be (D, 2, h, w), got {tuple(offsets.shape)}")
+    _expect("group_pixels: centre indices", idx, torch.int32)
+    if idx.dim() != 2 or idx.shape[0] != D:
+        raise HipError(f"group_pixels: centre indices must be ({D}, cap), got {tuple(idx.shape)}")
+    _expect("group_pixels: centre counts", cnt, torch.int32, (D,))
+    idx, cnt = idx.contiguous(), cnt.contiguous()
     offsets = offsets.contiguous()
     ids = torch.empty((D, h, w), dtype=torch.uint16, device=offsets.device)
     mask = 0
     for t in thing_list:
         mask |= 1 << int(t)
     if sem is not None:
-        assert sem.shape == (D, h, w) and sem.dtype == torch.uint8
+        _expect("group_pixels: class map", sem, torch.uint8, (D, h, w))
     work = torch.empty((query('emp_group_work_elems', D, idx.shape[1]),), dtype=torch.float32, device=offsets.device)
     call('emp_group_pixels', _ptr(idx), _ptr(cnt), idx.shape[1], _ptr(offsets), D, h, w, int(step),
          _ptr(sem.contiguous()) if sem is not None else None, mask, _ptr(work), _ptr(ids), stream())
@@ -256,7 +284,12 @@ def fuse_panoptic(sem, ids, cap, n_classes, thing_list, label_divisor, stuff_are
                   out_dtype=torch.uint32):
     """sem (D,H,W) u8, ids (D,H/up,W/up) u16 -> pan (D,H,W) uint32 or int64."""
     require_gpu()
+    _expect("fuse_panoptic: class map", sem, torch.uint8)
     D, H, W = sem.shape
+    up = int(up)
+    if up < 1 or H % up or W % up:
+        raise HipError(f"fuse_panoptic: a {H} x {W} class map is not {up} x the id map")
+    _expect("fuse_panoptic: ids", ids, (torch.uint16, torch.int16), (D, H // up, W // up))
     mask = 0
     for t in thing_list:
         mask |= 1 << int(t)
@@ -371,7 +404,9 @@ def sort_u64_i32(keys, vals, begin_bit=0, end_bit=64):
 def vote_ranges(starts, ends, grp, n_groups, vote_thr):
     """ranges (int64 cuda) tagged with int32 group ids -> (out_ranges (m,2) int64, out_off (n_groups+1) int32)."""
     require_gpu()
-    n = starts.numel()
+    n = _expect("vote_ranges: starts", starts, torch.int64).numel()
+    _expect("vote_ranges: ends", ends, torch.int64, numel=n)
+    _expect("vote_ranges: groups", grp, torch.int32, numel=n)
     dev = starts.device
     wb = query('emp_vote_work_bytes', n)
     work = torch.empty((wb,), dtype=torch.uint8, device=dev)
@@ -393,6 +428,13 @@ def rle_pair_intersections(starts, lens, inst_off, pairs):
 
 def fill_runs_u32(vol, starts, lens, order, ids):
     require_gpu()
+    _expect("fill_runs_u32: volume", vol, (torch.uint32, torch.int32))
+    n = _expect("fill_runs_u32: starts", starts, torch.int64).numel()
+    _expect("fill_runs_u32: lengths", lens, torch.int64, numel=n)
+    _expect("fill_runs_u32: order", order, torch.int32, numel=n)
+    _expect("fill_runs_u32: ids", ids, (torch.uint32, torch.int32))
+    if not (vol.is_contiguous() and starts.is_contiguous() and lens.is_contiguous() and order.is_contiguous()):
+        raise HipError("fill_runs_u32: operands must be contiguous")
     call('emp_fill_runs_u32', _ptr(vol), vol.numel(), _ptr(starts), _ptr(lens), _ptr(order), starts.numel(),
          _ptr(ids), stream())
     return vol
@@ -400,6 +442,9 @@ def fill_runs_u32(vol, starts, lens, order, ids):
 
 def fill_runs_u8(vol, starts, lens, value):
     require_gpu()
+    _expect("fill_runs_u8: volume", vol, torch.uint8)
+    n = _expect("fill_runs_u8: starts", starts, torch.int64).numel()
+    _expect("fill_runs_u8: lengths", lens, torch.int64, numel=n)
     call('emp_fill_runs_u8', _ptr(vol), vol.numel(), _ptr(starts), _ptr(lens), starts.numel(), int(value), stream())
     return vol
 

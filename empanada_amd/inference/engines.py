@@ -9,12 +9,14 @@ model and ``postprocess.panoptic_stack`` turns the resident head tensors into la
 kernel groups; results are identical to feeding the slices one by one.
 """
 import math
+import os
 from collections import deque
 
 import torch
 import torch.nn.functional as F
 
 from .. import _hip
+from .deferred import StackSession
 from .postprocess import (factor_pad, find_instance_center, get_panoptic_segmentation, group_pixels,
                           merge_semantic_and_instance, panoptic_stack)
 
@@ -74,6 +76,29 @@ class _MedianQueue:
 
     def reset(self):
         self.median_queue = deque(maxlen=self.ks)
+        self._session = None
+
+    # ---- deferred evaluation (inference/deferred.py) ----------------------------------------------------------
+    def _init_deferred(self, deferred, batch):
+        """deferred=None reads EMP_DEFERRED (default off: every call computes on the spot, like the reference)"""
+        if deferred is None:
+            deferred = os.environ.get('EMP_DEFERRED', '0') == '1'
+        self.deferred, self.deferred_batch = bool(deferred), int(batch)
+
+    def _open_session(self):
+        """the session the next image belongs to; an engine that is called again after end() without reset()
+        continues, like the reference's, with the queue as end() left it -- computed on the spot from then on"""
+        s = self._session
+        if s is not None and s.closed:
+            s.go_eager()
+            self.deferred, self._session, s = False, None, None
+        elif s is None:
+            s = self._session = StackSession(self, self.deferred_batch)
+        return s
+
+    def _end_deferred(self):
+        s = self._session
+        return [] if s is None else s.end()
 
     def enqueue(self, item):
         self.median_queue.append(item)
@@ -171,22 +196,40 @@ class PanopticDeepLabEngine3d(_MedianQueue, PanopticDeepLabEngine):
     fills, ``end()`` flushes the last ks // 2 slices (engines.py:161-221)."""
 
     def __init__(self, model, thing_list, label_divisor=1000, stuff_area=64, void_label=0, nms_threshold=0.1,
-                 nms_kernel=7, confidence_thr=0.5, median_kernel_size=3, **kwargs):
+                 nms_kernel=7, confidence_thr=0.5, median_kernel_size=3, deferred=None, deferred_batch=16, **kwargs):
         super().__init__(model=model, thing_list=thing_list, label_divisor=label_divisor, stuff_area=stuff_area,
                          void_label=void_label, nms_threshold=nms_threshold, nms_kernel=nms_kernel,
                          confidence_thr=confidence_thr, median_kernel_size=median_kernel_size, **kwargs)
+        self._init_deferred(deferred, deferred_batch)
 
     def __call__(self, image):
         _check_single_image(image)
+        if self.deferred:
+            session = self._open_session()
+            if session is not None:
+                return session.add(self.to_model_device(image))
         self.enqueue(self.infer(self.to_model_device(image)))
         ready = self.get_next(keys=['sem'])
         return None if ready is None else self._labels_of(ready)
 
     def end(self):
+        return self._end_deferred() if self.deferred else self._end_now()
+
+    def _end_now(self, upsampling=1):
         tail = _MedianQueue.end(self)
         for heads in tail:                                 # the reference leaves the hardened map in the queue item
             heads['sem'] = self._harden_seg(heads['sem'])
         return [self.postprocess(heads['sem'], heads['ctr_hmp'], heads['offsets']) for heads in tail]
+
+    # what a deferred session calls
+    def _labels_now(self, ready, upsampling=1):
+        return self._labels_of(ready)
+
+    def _deferred_infer(self, x, upsampling=1):
+        return self.infer(x)
+
+    def _deferred_stack(self, heads, upsampling=1):
+        return self.postprocess_stack(heads, coarse_boundaries=False, upsampling=1)
 
 
 class PanopticDeepLabRenderEngine(PanopticDeepLabEngine):
@@ -235,12 +278,17 @@ class PanopticDeepLabRenderEngine(PanopticDeepLabEngine):
     def postprocess(self, sem, instance_cells):
         return self.get_panoptic_seg(self._harden_seg(sem)[0], instance_cells)
 
-    def _padded_heads(self, image, upsampling):
-        """pad, move to the model's device, forward with 2 + log2(upsampling) render steps"""
+    @staticmethod
+    def _render_steps(upsampling):
         extra = math.log(upsampling, 2)
         assert extra.is_integer(), "Upsampling factor not log base 2!"
+        return int(2 + extra)
+
+    def _padded_heads(self, image, upsampling):
+        """pad, move to the model's device, forward with 2 + log2(upsampling) render steps"""
+        steps = self._render_steps(upsampling)
         _check_single_image(image)
-        return self.infer(self.to_model_device(factor_pad(image, self.padding_factor)), int(2 + extra))
+        return self.infer(self.to_model_device(factor_pad(image, self.padding_factor)), steps)
 
     def _cropped_labels(self, heads, size, upsampling):
         cells = self.get_instance_cells(heads['ctr_hmp'], heads['offsets'], upsampling)
@@ -261,13 +309,20 @@ class PanopticDeepLabRenderEngine3d(_MedianQueue, PanopticDeepLabRenderEngine):
 
     def __init__(self, model, thing_list, label_divisor=1000, stuff_area=64, void_label=0, nms_threshold=0.1,
                  nms_kernel=7, confidence_thr=0.5, median_kernel_size=3, padding_factor=16, coarse_boundaries=True,
-                 **kwargs):
+                 deferred=None, deferred_batch=16, **kwargs):
         super().__init__(model=model, thing_list=thing_list, label_divisor=label_divisor, stuff_area=stuff_area,
                          void_label=void_label, nms_threshold=nms_threshold, nms_kernel=nms_kernel,
                          confidence_thr=confidence_thr, median_kernel_size=median_kernel_size,
                          padding_factor=padding_factor, coarse_boundaries=coarse_boundaries)
+        self._init_deferred(deferred, deferred_batch)
 
     def __call__(self, image, size, upsampling=1):
+        if self.deferred:
+            session = self._open_session()
+            if session is not None:
+                self._render_steps(upsampling)
+                _check_single_image(image)
+                return session.add(self.to_model_device(factor_pad(image, self.padding_factor)), size, upsampling)
         heads = self._padded_heads(image, upsampling)
         heads['size'] = size
         self.enqueue(heads)
@@ -275,7 +330,20 @@ class PanopticDeepLabRenderEngine3d(_MedianQueue, PanopticDeepLabRenderEngine):
         return None if ready is None else self._cropped_labels(ready, ready['size'], upsampling)
 
     def end(self, upsampling=1):
+        return self._end_deferred() if self.deferred else self._end_now(upsampling)
+
+    def _end_now(self, upsampling=1):
         return [self._cropped_labels(heads, heads['size'], upsampling) for heads in _MedianQueue.end(self)]
+
+    # what a deferred session calls
+    def _labels_now(self, ready, upsampling=1):
+        return self._cropped_labels(ready, ready['size'], upsampling)
+
+    def _deferred_infer(self, x, upsampling=1):
+        return self.infer(x, self._render_steps(upsampling))
+
+    def _deferred_stack(self, heads, upsampling=1):
+        return self.postprocess_stack(heads, upsampling)
 
 
 class MultiGPUInferenceEngine(PanopticDeepLabRenderEngine):

@@ -25,6 +25,7 @@ from ..array_utils import numpy_fill_instances
 from ..consensus import merge_objects_from_trackers, merge_semantic_from_trackers
 from ..zarr_utils import zarr_fill_instances
 from . import filters
+from .deferred import LazyFinal, LazySeg
 from .engines import _MedianQueue
 from .matcher import RLEMatcher
 from .postprocess import merge_semantic_and_instance
@@ -53,7 +54,17 @@ def create_axis_trackers(axes, class_labels, label_divisor, shape):
 
 
 def apply_matchers(rle_seg, matchers):
-    """patterns.py:55-66"""
+    """patterns.py:55-66.  A handle of a deferred stack (inference/deferred.py) is recorded and returned as it is."""
+    if isinstance(rle_seg, LazySeg):
+        session = rle_seg._s
+        if not session.lazy_apply(rle_seg, matchers):
+            _apply_matchers_now(rle_seg._force(), matchers)
+            session.note_applied_now(rle_seg)
+        return rle_seg
+    return _apply_matchers_now(rle_seg, matchers)
+
+
+def _apply_matchers_now(rle_seg, matchers):
     for matcher in matchers:
         class_id = matcher.class_id
         if matcher.target_rle is None:
@@ -80,7 +91,19 @@ def forward_matching(matchers, queue, rle_stack, matcher_in, labels, label_divis
 
 
 def backward_matching(rle_stack, matchers, axis_len):
-    """patterns.py:102-121"""
+    """patterns.py:102-121.  Over the handles of one deferred stack (all of them, in order, straight from
+    apply_matchers) it yields handles; the label propagation then runs once, over the whole stack, when the
+    trackers are finished."""
+    first = rle_stack[0] if len(rle_stack) else None
+    if isinstance(first, LazySeg) and first._s.lazy_backward(rle_stack, matchers, axis_len):
+        session = first._s
+        for rev_idx in range(axis_len - 1, -1, -1):
+            yield rev_idx, (LazyFinal(session, rev_idx) if session.bwd == 'lazy' else session.bwd_real[rev_idx])
+        return
+    yield from _backward_matching_now(rle_stack, matchers, axis_len)
+
+
+def _backward_matching_now(rle_stack, matchers, axis_len):
     for matcher in matchers:
         matcher.target_rle = None
         matcher.assign_new = False

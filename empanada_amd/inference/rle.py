@@ -13,6 +13,7 @@ import torch
 
 from .. import _hip
 from ..array_utils import string_to_rle
+from .deferred import LazyPan
 
 __all__ = ['pan_seg_to_rle_seg', 'rle_seg_to_pan_seg', 'unpack_rle_attrs', 'connected_components',
            'stack_to_rle_segs', 'runs_to_instances']
@@ -85,7 +86,13 @@ def stack_to_rle_segs(pan, labels, label_divisor, thing_list, force_connected=Tr
 
 
 def pan_seg_to_rle_seg(pan_seg, labels, label_divisor, thing_list, force_connected=True):
-    """Reference signature (rle.py:26-86).  pan_seg: (h, w) array or tensor of panoptic labels."""
+    """Reference signature (rle.py:26-86).  pan_seg: (h, w) array or tensor of panoptic labels -- or the handle a
+    deferred 3d engine hands out (inference/deferred.py), in which case a handle comes back."""
+    if isinstance(pan_seg, LazyPan):
+        seg = pan_seg._s.lazy_rle(pan_seg, (labels, label_divisor, thing_list, force_connected))
+        if seg is not None:
+            return seg
+        pan_seg = pan_seg._force()
     pan = _to_device_u32(pan_seg)
     assert pan.dim() == 2, "pan_seg must be (h, w)"
     segs, _ = stack_to_rle_segs(pan[None].contiguous(), labels, label_divisor, thing_list, force_connected)

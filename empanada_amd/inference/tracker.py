@@ -22,6 +22,7 @@ import json
 import numpy as np
 
 from ..array_utils import merge_boxes, rle_decode, rle_encode, rle_to_string, string_to_rle
+from .deferred import LazyClass, LazyInstances
 
 __all__ = ['InstanceTracker', 'to_box3d', 'to_coords3d']
 
@@ -88,6 +89,17 @@ class InstanceTracker:
         missing = [n for n in ('class_id', 'label_divisor', 'shape3d') if getattr(self, n) is None]
         assert not missing, f"tracker is missing {missing}"
         assert not self.finished, "Cannot update tracker after calling finish!"
+        if isinstance(instance_rles, LazyClass) and instance_rles._s.bwd == 'lazy':
+            # a handle of a deferred stack (inference/deferred.py): filed by finish(), or by the first look inside
+            held = self.instances
+            if type(held) is dict and not held:
+                held = self.instances = LazyInstances(self)
+            if isinstance(held, LazyInstances) and not held._resolved:
+                held.record(instance_rles, index2d)
+                return
+        self._update_now(instance_rles, index2d)
+
+    def _update_now(self, instance_rles, index2d):
         for label, piece in instance_rles.items():
             box = to_box3d(index2d, piece['box'], self.axis)
             starts, runs = self._lift(piece['starts'], piece['runs'], index2d)
@@ -101,6 +113,18 @@ class InstanceTracker:
 
     def finish(self):
         """lists of per-slice pieces -> one (starts, runs) pair per instance; yz pixels are sorted and re-encoded"""
+        held = self.instances
+        if isinstance(held, LazyInstances):
+            session = held.fast_ok()
+            if session is not None:
+                # every slice of a deferred stack, last to first, and nobody looked: the whole-stack path
+                final = dict(session.tracker_instances(self.axis, self.shape3d, self.class_id))
+                held.fill(final)
+                self.instances = final
+                self.finished = True
+                return
+            held.resolve()
+            self.instances = dict.copy(held)
         for entry in self.instances.values():
             if not isinstance(entry['starts'], list):
                 continue                                   # assigned in final form by a caller

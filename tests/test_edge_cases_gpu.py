@@ -121,6 +121,16 @@ def test_argument_errors_are_loud():
     from empanada_amd.inference.postprocess import group_pixels, panoptic_stack
     with pytest.raises(ValueError):
         group_pixels(torch.zeros(1, 2, dtype=torch.long), torch.zeros(2, 2, 8, 8))
+    with pytest.raises(_hip.HipError):     # a queue item of another shape would be read out of bounds by the kernel
+        _hip.median_step([torch.rand(1, 1, 8, 8).cuda(), torch.rand(0, 1, 8, 8).cuda(), torch.rand(1, 1, 8, 8).cuda()])
+    with pytest.raises(_hip.HipError):
+        _hip.median_step([torch.rand(1, 1, 8, 8).cuda().double()] * 3)
+    with pytest.raises(_hip.HipError):     # ids at another resolution than the class map / up
+        _hip.fuse_panoptic(torch.zeros(1, 8, 8, dtype=torch.uint8).cuda(),
+                           torch.zeros(1, 4, 4, dtype=torch.int16).cuda(), 4, 2, [1], 1000, 16, 0, up=1)
+    with pytest.raises(_hip.HipError):     # one centre list per slice
+        _hip.group_pixels(torch.zeros(1, 4, dtype=torch.int32).cuda(), torch.zeros(2, dtype=torch.int32).cuda(),
+                          torch.zeros(2, 2, 8, 8).cuda(), 1)
     with pytest.raises(_hip.HipError):     # heads at a resolution the step does not explain
         panoptic_stack(torch.rand(2, 1, 30, 30).cuda(), torch.rand(2, 1, 30, 30).cuda(), torch.rand(2, 2, 30, 30).cuda(),
                        coarse_boundaries=True, **KW)

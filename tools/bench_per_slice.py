@@ -3,13 +3,17 @@ time: engine(image) -> pan_seg_to_rle_seg -> apply_matchers, then engine.end(), 
 finish, filters, fill -- next to the whole-stack protocol bench.py times.  The model forward runs on every slice
 (batch 1, timed); its outputs are replaced by the planted heads of that slice so that the post-processing sees a
 realistic object load (same convention as bench.py).
-usage: PYTHONPATH=. python tools/bench_per_slice.py [n_slices] [plain|tuned|graph]"""
+`deferred` = the same calls with a deferred engine (empanada_amd/inference/deferred.py): the functions hand handles on
+and the stack is evaluated once, in finish_tracking, by the whole-stack path (forward in batches of 16).
+usage: PYTHONPATH=. python tools/bench_per_slice.py [n_slices] [plain|tuned|graph|deferred] [S]"""
+import os
 import sys
 import time
 
 import numpy as np
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from empanada_amd.inference import engines as EN
 from empanada_amd.inference import filters
@@ -34,27 +38,30 @@ class PlantedModel(torch.nn.Module):
         e1.record()
         self.events.append((e0, e1))
         self.checksum += out['sem_logits'].float().sum(dtype=torch.float64)
-        t, self.t = self.t, self.t + 1
-        p = self.heads['sem'][t:t + 1].clamp(1e-6, 1 - 1e-6)
-        return {'sem_logits': torch.log(p / (1 - p)), 'ctr_hmp': self.heads['ctr_hmp'][t:t + 1],
-                'offsets': self.heads['offsets'][t:t + 1]}
+        n = x.size(0)
+        t, self.t = self.t, self.t + n
+        p = self.heads['sem'][t:t + n].clamp(1e-6, 1 - 1e-6)
+        return {'sem_logits': torch.log(p / (1 - p)), 'ctr_hmp': self.heads['ctr_hmp'][t:t + n],
+                'offsets': self.heads['offsets'][t:t + n]}
 
 
 def main():
     D = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    S = 512
+    S = int(sys.argv[3]) if len(sys.argv) > 3 else 512
     dev = torch.device('cuda')
     vol, heads, n_obj = bench.build_inputs(D, S, dev)
     net = prepare_for_inference(bench.build_model('pdl_r50'), dev)
     mode = sys.argv[2] if len(sys.argv) > 2 else 'plain'            # plain | tuned | graph (= tuned + HIP graph)
-    if mode in ('tuned', 'graph'):
-        x1 = torch.rand((1, 1, S, S), device=dev).contiguous(memory_format=torch.channels_last)
+    deferred = mode == 'deferred'
+    B = 16 if deferred else 1
+    if mode in ('tuned', 'graph', 'deferred'):
+        x1 = torch.rand((B, 1, S, S), device=dev).contiguous(memory_format=torch.channels_last)
         rep = tune_fused_convs(net, x1)
         counts = {}
         for best, _ in rep.values():
             counts[best] = counts.get(best, 0) + 1
-        print('conv sites at batch 1:', counts)
-    if mode == 'graph':
+        print(f'conv sites at batch {B}:', counts)
+    if mode in ('graph', 'deferred'):
         net = GraphedForward(net)
     model = PlantedModel(net, heads).eval()
     labels, thing, div = [1], bench.ENGINE['thing_list'], bench.ENGINE['label_divisor']
@@ -69,7 +76,7 @@ def main():
         model.t = 0
         model.events = []
         stages.clear()
-        eng = EN.PanopticDeepLabEngine3d(model, **bench.ENGINE)
+        eng = EN.PanopticDeepLabEngine3d(model, deferred=deferred, deferred_batch=B, **bench.ENGINE)
         matchers = PA.create_matchers(thing, div, bench.MATCH['merge_iou_thr'], bench.MATCH['merge_ioa_thr'])
         trackers = PA.create_axis_trackers({'xy': 0}, labels, div, (D, S, S))['xy']
         torch.cuda.synchronize()
@@ -99,7 +106,7 @@ def main():
         for tr in trackers:
             filters.remove_small_objects(tr, min_size=bench.FILTERS['min_size'])
             filters.remove_pancakes(tr, min_span=bench.FILTERS['min_span'])
-        tick('backward matching + trackers + filters', t0)
+        tick('backward matching + trackers (deferred: the whole stack is evaluated here) + filters', t0)
         t0 = time.perf_counter()
         out = np.zeros((D, S, S), dtype=np.uint32)
         for tr in trackers:
@@ -111,7 +118,7 @@ def main():
     fwd = sum(a.elapsed_time(b) for a, b in model.events) * 1e-3
     print(f'  of the engine time, model forward (HIP events): {fwd:.3f} s = {fwd / D * 1e3:.2f} ms / slice')
     for k, v in stages.items():
-        print(f'  {k:42s} {v:7.3f} s  {100 * v / dt:5.1f} %')
+        print(f'  {k:86s} {v:7.3f} s  {100 * v / dt:5.1f} %')
 
 
 if __name__ == '__main__':
