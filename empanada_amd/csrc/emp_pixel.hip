@@ -271,60 +271,111 @@ __global__ __launch_bounds__(256) void find_centers_kernel(const float *__restri
 {
     const int d = blockIdx.y;
     const float *img = hmp + (int64_t)d * h * w;
-    const int64_t hw = (int64_t)h * w;
+    const uint32_t hw = (uint32_t)h * (uint32_t)w;                  // < 2^31 (checked by the entry point)
     const int lane = threadIdx.x & 63;
     const bool need_left = (k / 2) >= 1, need_right = (k - 1 - k / 2) >= 1;
     // wave-uniform loop bounds: all 64 lanes take part in the shuffles of every iteration.  Each lane issues
-    // FC_U independent 16-byte loads before touching any of them (4 KiB in flight per wave).
+    // FC_U independent 16-byte loads before touching any of them (4 KiB in flight per wave); the two values a wave
+    // cannot get from a neighbouring lane (left of lane 0, right of lane 63) are requested in the same phase, so that
+    // no load sits between the streaming loads and their use.
     constexpr int FC_U = 4;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * VEC;
-    const int64_t wave_q0 = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * VEC;
-    for (int64_t base0 = wave_q0; base0 < hw; base0 += stride * FC_U) {
-        float vv[FC_U][VEC];
+    const uint32_t stride = gridDim.x * blockDim.x * VEC;
+    const uint32_t wave_q0 = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) * VEC;
+    // pixel coordinates advance by a fixed step from load to load: one division per lane for the whole kernel (the
+    // kernel was bound by its vector instructions -- ~37 per pixel, a wave64 instruction takes 4 cycles --, not by HBM)
+    const int step_y = (int)(stride / (uint32_t)w), step_x = (int)(stride % (uint32_t)w);
+    int y_run = (int)((wave_q0 + (uint32_t)lane * VEC) / (uint32_t)w);
+    int x_run = (int)((wave_q0 + (uint32_t)lane * VEC) % (uint32_t)w);
+    const float nl = need_left ? 0.f : -INFINITY, nr = need_right ? 0.f : -INFINITY;   // + 0 keeps, + -inf drops a side
+    for (uint64_t base0 = wave_q0; base0 < hw; base0 += (uint64_t)stride * FC_U) {
+        float vv[FC_U][VEC], edge[FC_U];
+        int yy[FC_U], xx[FC_U];
 #pragma unroll
         for (int u = 0; u < FC_U; ++u) {
-            const int64_t q = base0 + u * stride + (int64_t)lane * VEC;
+            const uint64_t q64 = base0 + (uint64_t)u * stride + (uint32_t)lane * VEC;
+            const bool live = q64 < hw;
+            const uint32_t q = live ? (uint32_t)q64 : 0u;
             if (VEC == 4) {
-                float4 f = (q < hw) ? *reinterpret_cast<const float4 *>(img + q) : make_float4(-1.f, -1.f, -1.f, -1.f);
+                float4 f = live ? *reinterpret_cast<const float4 *>(img + q) : make_float4(-1.f, -1.f, -1.f, -1.f);
                 vv[u][0] = f.x; vv[u][1] = f.y; vv[u][2] = f.z; vv[u][3] = f.w;
             } else {
-                vv[u][0] = (q < hw) ? img[q] : -1.f;
+                vv[u][0] = live ? img[q] : -1.f;
             }
+            const int y = y_run, x = x_run;
+            yy[u] = y; xx[u] = x;
+            x_run += step_x; y_run += step_y;
+            if (x_run >= w) { x_run -= w; ++y_run; }
+            edge[u] = -INFINITY;
+            if (lane == 0 && live && x > 0) edge[u] = img[q - 1];
+            if (lane == 63 && live && x + VEC < w) edge[u] = img[q + VEC];
         }
+        // phase 1, registers only: pixels above the threshold that are >= their in-row neighbours -- the ridge of every
+        // blob, one pixel per blob row.  For a pixel c > thr, c > 0 the reference's comparison with a neighbour n,
+        // thresholded(n) > c, is n > c (n > c > thr passes the threshold; n <= thr compares as -1, never above c > 0).
+        unsigned ridge = 0;
 #pragma unroll
         for (int u = 0; u < FC_U; ++u) {
-            const int64_t base = base0 + u * stride;
-            if (base >= hw) break;                                   // wave-uniform
-            const int64_t q = base + (int64_t)lane * VEC;
-            const bool live = q < hw;
+            const uint64_t base = base0 + (uint64_t)u * stride;
+            if (base >= hw) break;                                   // wave-uniform; dead lanes hold -1: never a ridge
+            const int x = xx[u];
             float v[VEC + 2];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) v[j + 1] = vv[u][j];
-            const int y = live ? (int)(q / w) : 0, x = live ? (int)(q % w) : 0;
             float left = __shfl_up(v[VEC], 1), right = __shfl_down(v[1], 1);
-            // neighbours across the wave edge or the row edge come from memory (or do not exist)
-            if (lane == 0 || x == 0) left = (live && x > 0) ? img[q - 1] : -INFINITY;
-            if (lane == 63 || x + VEC >= w) right = (live && x + VEC < w) ? img[q + VEC] : -INFINITY;
+            // neighbours across the wave edge come from memory, neighbours across the row edge do not exist
+            if (lane == 0) left = edge[u];
+            if (lane == 63) right = edge[u];
+            if (x == 0) left = -INFINITY;
+            if (x + VEC >= w) right = -INFINITY;
             v[0] = left;
             v[VEC + 1] = right;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                float c = v[j + 1];
-                bool cand = live && c > thr && c > 0.0f;
-                if (cand && need_left && x + j > 0 && thresholded(v[j], thr) > c) cand = false;
-                if (cand && need_right && x + j + 1 < w && thresholded(v[j + 2], thr) > c) cand = false;
-                // survivors of the in-row test (the ridge of every blob) are settled by the whole wave: the k x k
-                // window is fetched by k*k lanes at once and reduced with cross-lane maxima
-                unsigned long long todo = __ballot(cand);
+                const float c = v[j + 1];
+                if (c > thr && c > 0.0f && !(v[j] + nl > c) && !(v[j + 2] + nr > c)) ridge |= 1u << (u * VEC + j);
+            }
+        }
+        if (!__ballot(ridge != 0)) continue;
+        // phase 2: the pixels straight above and below (in the window under the same conditions as left / right) leave
+        // the summit of a blob only.  All loads of the phase are issued before the first comparison (rows other waves
+        // are streaming: L2 hits)
+        float up_v[FC_U * VEC], dn_v[FC_U * VEC];
+#pragma unroll
+        for (int u = 0; u < FC_U; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int b = u * VEC + j;
+                up_v[b] = dn_v[b] = -INFINITY;
+                if ((ridge >> b) & 1u) {
+                    const uint32_t q = (uint32_t)yy[u] * (uint32_t)w + (uint32_t)(xx[u] + j);
+                    if (need_left && yy[u] > 0) up_v[b] = img[q - w];
+                    if (need_right && yy[u] + 1 < h) dn_v[b] = img[q + w];
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < FC_U; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int b = u * VEC + j;
+                if (((ridge >> b) & 1u) && (up_v[b] > vv[u][j] || dn_v[b] > vv[u][j])) ridge &= ~(1u << b);
+            }
+        // phase 3: the survivors are settled by the whole wave: the k x k window is fetched by k*k lanes at once and
+        // reduced with cross-lane maxima
+#pragma unroll
+        for (int u = 0; u < FC_U; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int b = u * VEC + j;
+                unsigned long long todo = __ballot((ridge >> b) & 1u);
                 while (todo) {
                     const int src = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
-                    const int cy = __shfl(y, src), cx = __shfl(x, src) + j;
-                    const float cv = __shfl(c, src);
+                    const int cy = __shfl(yy[u], src), cx = __shfl(xx[u], src) + j;
+                    const float cv = __shfl(vv[u][j], src);
                     float m = -INFINITY;
                     for (int t = lane; t < k * k; t += 64) {
-                        int yy = cy - k / 2 + t / k, xx = cx - k / 2 + t % k;
-                        if (yy >= 0 && yy < h && xx >= 0 && xx < w) m = fmaxf(m, thresholded(img[(int64_t)yy * w + xx], thr));
+                        int y2 = cy - k / 2 + t / k, x2 = cx - k / 2 + t % k;
+                        if (y2 >= 0 && y2 < h && x2 >= 0 && x2 < w) m = fmaxf(m, thresholded(img[(int64_t)y2 * w + x2], thr));
                     }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -334,7 +385,6 @@ __global__ __launch_bounds__(256) void find_centers_kernel(const float *__restri
                     }
                 }
             }
-        }
     }
 }
 
@@ -382,7 +432,9 @@ extern "C" int emp_find_centers(const float *hmp, int D, int h, int w, float thr
     const bool vec4 = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(hmp) & 15) == 0);
     const int64_t hw = (int64_t)h * w;
     if (vec4) {
-        int gx = emp_grid(emp_cdiv(hw / 4, 4), 256, 512);
+        // 64 float4 per lane = 16 trips of the 4-load loop: few, long-lived blocks (one trip per lane: 1.52 ms per
+        // 1024^3 plane, 16 trips: 1.27 ms)
+        int gx = emp_grid(emp_cdiv(hw / 4, 64), 256, 512);
         hipLaunchKernelGGL(find_centers_kernel<4>, dim3(gx, D), dim3(256), 0, st, hmp, h, w, thr, k, cap, out_idx,
                            out_count);
     } else {
@@ -887,6 +939,71 @@ __global__ __launch_bounds__(256) void fuse_apply_vec4_kernel(const uint8_t *__r
     }
 }
 
+// uint32 labels, FA_U independent 4-pixel items per lane: every wave instruction still covers one contiguous segment
+// (256 B of classes, 512 B of ids, 1 KiB of labels -- a lane that owned 16 consecutive pixels would store 16-byte pieces
+// 64 bytes apart, which measured 25-45 % SLOWER), but the loads of all items are issued before the first label is formed,
+// so a lane has FA_U x 28 bytes in flight.  The per-class "keep this stuff class" flags become a bit mask in a scalar
+// register; the label table is only touched by thing pixels.
+#define FA_U 4
+__global__ __launch_bounds__(256) void fuse_apply_multi_kernel(const uint8_t *__restrict__ sem,
+                                                               const uint16_t *__restrict__ ids, int H, int W, int up,
+                                                               int cap, int nc, uint32_t thing_mask, int64_t div,
+                                                               int64_t void_label, const int32_t *__restrict__ lut,
+                                                               const int32_t *__restrict__ ok,
+                                                               uint32_t *__restrict__ out)
+{
+    const int d = blockIdx.y;
+    const int64_t HW = (int64_t)H * W;
+    const int w = W / up;
+    const uint8_t *s = sem + (int64_t)d * HW;
+    const uint16_t *g = ids + (int64_t)d * (H / up) * w;
+    const uint32_t *ll = reinterpret_cast<const uint32_t *>(lut) + (int64_t)d * (cap + 1);
+    const int32_t *oo = ok + (int64_t)d * nc;
+    uint32_t *o = out + (int64_t)d * HW;
+    uint32_t okmask = 0;
+    for (int c = 0; c < nc; ++c) okmask |= oo[c] ? (1u << c) : 0u;          // wave-uniform: scalar loads
+    const uint32_t vlab = (uint32_t)void_label, udiv = (uint32_t)div;
+    const int64_t n4 = HW / 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < n4; q0 += stride * FA_U) {
+        uint32_t cw[FA_U];
+        uint2 iw[FA_U];
+#pragma unroll
+        for (int u = 0; u < FA_U; ++u) {
+            const int64_t q = q0 + u * stride;
+            cw[u] = 0; iw[u] = make_uint2(0, 0);
+            if (q < n4) {
+                const int64_t p = q * 4;
+                cw[u] = *reinterpret_cast<const uint32_t *>(s + p);
+                if (up == 1) {
+                    iw[u] = *reinterpret_cast<const uint2 *>(g + p);
+                } else {
+                    const uint32_t p32 = (uint32_t)p, W32 = (uint32_t)W;      // a slice has < 2^31 pixels here
+                    const uint32_t v = g[(int64_t)((p32 / W32) / (uint32_t)up) * w + (p32 % W32) / (uint32_t)up];
+                    iw[u] = make_uint2(v | (v << 16), v | (v << 16));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FA_U; ++u) {
+            const int64_t q = q0 + u * stride;
+            if (q < n4) {
+                uint32_t r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t c = (cw[u] >> (8 * j)) & 0xffu;
+                    c = c < (uint32_t)nc ? c : (uint32_t)(nc - 1);
+                    const uint32_t id = ((j < 2 ? iw[u].x : iw[u].y) >> (16 * (j & 1))) & 0xffffu;
+                    uint32_t v = ((okmask >> c) & 1u) ? c * udiv : vlab;
+                    if (((thing_mask >> c) & 1u) && id > 0) v = ll[id];
+                    r[j] = v;
+                }
+                *reinterpret_cast<uint4 *>(o + q * 4) = make_uint4(r[0], r[1], r[2], r[3]);
+            }
+        }
+    }
+}
+
 // 4 pixels per lane for the histogram pass (same loads as above); sub-position j of all lanes is
 // aggregated across the wave before touching the block-local LDS bins.
 __global__ __launch_bounds__(256) void fuse_hist_vec4_kernel(const uint8_t *__restrict__ sem,
@@ -1030,7 +1147,11 @@ extern "C" int emp_fuse_apply(const uint8_t *sem, const uint16_t *ids, int D, in
     int64_t HW = (int64_t)H * W;
     int gx = emp_grid(HW, 256, 1024);
     const bool vec4 = fuse_vec4_ok(sem, ids, out_pan_u32 ? (void *)out_pan_u32 : (void *)out_pan_i64, W, up);
-    if (vec4) {
+    if (vec4 && out_pan_u32 && HW < (1LL << 31)) {
+        int gv = emp_grid(emp_cdiv(HW / 4, FA_U), 256, 1024);           // one trip of FA_U items per lane
+        hipLaunchKernelGGL(fuse_apply_multi_kernel, dim3(gv, D), dim3(256), 0, st, sem, ids, H, W, up, cap, n_classes,
+                           thing_mask, label_divisor, void_label, work + L.lut, work + L.ok, out_pan_u32);
+    } else if (vec4) {
         int gv = emp_grid(HW / 4, 256, 1024);
         if (out_pan_u32)
             hipLaunchKernelGGL(fuse_apply_vec4_kernel<uint32_t>, dim3(gv, D), dim3(256), 0, st, sem, ids, H, W, up,
