@@ -250,10 +250,18 @@ def numpy_fill_instances(volume, instances):
     runs = [np.asarray(instances[k]['runs'], dtype=np.int64) for k in ids]
     order = np.repeat(np.arange(len(ids), dtype=np.int32), [len(s) for s in starts])
     flat = volume.reshape(-1)
-    if volume.dtype.itemsize > 4 or int(max(ids)) >= 2 ** 31 or (flat.size and int(flat.max()) >= 2 ** 31):
+    top = int(flat.max()) if flat.size else 0
+    if volume.dtype.itemsize > 4 or int(max(ids)) >= 2 ** 31 or top >= 2 ** 31:
         raise ValueError("fill: ids must be < 2^31 and the volume at most 32-bit")
-    dvol = _hip.np_to_dev_u32(flat)
+    if top > 0 or (volume.dtype.kind == 'i' and flat.size and int(flat.min()) < 0):
+        dvol = _hip.np_to_dev_u32(flat)
+    else:                                        # a fresh volume (the usual case): nothing to upload
+        dvol = torch.zeros((flat.size,), dtype=torch.int32, device='cuda').view(torch.uint32)
     _hip.fill_runs_u32(dvol, _dev(np.concatenate(starts), np.int64), _dev(np.concatenate(runs), np.int64),
                        _dev(order, np.int32), _hip.np_to_dev_u32(np.asarray(ids, dtype=np.int64)))
-    flat[:] = dvol.cpu().numpy().astype(volume.dtype)
+    if volume.dtype.itemsize == 4 and volume.dtype.kind in 'ui' and flat.flags.c_contiguous and flat.flags.writeable \
+            and np.shares_memory(flat, volume):
+        torch.from_numpy(flat.view(np.int32)).copy_(dvol.view(torch.int32))     # straight into the caller's memory
+    else:
+        flat[:] = dvol.cpu().numpy().astype(volume.dtype)
     return flat.reshape(volume.shape)
