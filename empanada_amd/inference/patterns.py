@@ -100,6 +100,10 @@ def backward_matching(rle_stack, matchers, axis_len):
         for rev_idx in range(axis_len - 1, -1, -1):
             yield rev_idx, (LazyFinal(session, rev_idx) if session.bwd == 'lazy' else session.bwd_real[rev_idx])
         return
+    # computed on the spot: what apply_matchers recorded for handles in the stack is filed first, so that the
+    # matchers are where the reference's forward pass leaves them BEFORE they are reset for the backward pass
+    for session in {id(x._s): x._s for x in rle_stack if isinstance(x, LazySeg)}.values():
+        session._forward_now()
     yield from _backward_matching_now(rle_stack, matchers, axis_len)
 
 
