@@ -127,6 +127,10 @@ def load():
 
 
 def require_gpu():
+    if torch.cuda._is_in_bad_fork():
+        raise HipError("this process was forked from one that had initialised the GPU: HIP cannot be used here.  Start "
+                       "the process with the 'spawn' method (multiprocessing.set_start_method('spawn')), or call "
+                       "patterns.forward_matching / forward_multigpu, which re-start themselves that way")
     if not torch.cuda.is_available():
         raise HipError("empanada_amd needs an MI355X (HIP device) for this operation; no CPU fallback exists")
 

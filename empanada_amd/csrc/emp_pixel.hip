@@ -1117,23 +1117,37 @@ __global__ __launch_bounds__(256) void fuse_hist_vec4_kernel(const uint8_t *__re
     const int64_t span = (n4 + gridDim.x - 1) / gridDim.x;
     const int64_t q0 = (int64_t)blockIdx.x * span;
     const int64_t q1 = (q0 + span < n4) ? q0 + span : n4;
+    // the loads of the NEXT two trips are in flight while a trip is binned (one trip at a time ran at 2.2 TB/s)
+    uint32_t cw[3] = {0, 0, 0};
+    uint2 iw[3] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
+    auto fetch = [&](int64_t q, uint32_t &c, uint2 &i) {
+        c = 0; i = make_uint2(0, 0);
+        if (q < q1) {
+            const int64_t p = q * 4;
+            c = *reinterpret_cast<const uint32_t *>(s + p);
+            if (up == 1) {
+                i = *reinterpret_cast<const uint2 *>(g + p);
+            } else {
+                const uint32_t p32 = (uint32_t)p, W32 = (uint32_t)W;       // HW < 2^31 (checked by the launcher)
+                const uint32_t v = g[(int64_t)((p32 / W32) / (uint32_t)up) * w + (p32 % W32) / (uint32_t)up];
+                i = make_uint2(v | (v << 16), v | (v << 16));
+            }
+        }
+    };
+    fetch(q0 + threadIdx.x, cw[0], iw[0]);
+    fetch(q0 + blockDim.x + threadIdx.x, cw[1], iw[1]);
     for (int64_t qq = q0; qq < q1; qq += blockDim.x) {
         int64_t q = qq + threadIdx.x;
         bool live = q < q1;
-        int cls[4] = {0, 0, 0, 0}, id[4] = {0, 0, 0, 0};
-        if (live) {
-            const int64_t p = q * 4;
-            uchar4 c4 = *reinterpret_cast<const uchar4 *>(s + p);
-            cls[0] = c4.x; cls[1] = c4.y; cls[2] = c4.z; cls[3] = c4.w;
-            if (up == 1) {
-                ushort4 i4 = *reinterpret_cast<const ushort4 *>(g + p);
-                id[0] = i4.x; id[1] = i4.y; id[2] = i4.z; id[3] = i4.w;
-            } else {
-                int y = (int)(p / W), x = (int)(p % W);
-                int v = g[(int64_t)(y / up) * w + x / up];
-                id[0] = id[1] = id[2] = id[3] = v;
-            }
+        fetch(q + 2 * (int64_t)blockDim.x, cw[2], iw[2]);
+        int cls[4], id[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cls[j] = (int)((cw[0] >> (8 * j)) & 0xffu);
+            id[j] = (int)(((j < 2 ? iw[0].x : iw[0].y) >> (16 * (j & 1))) & 0xffffu);
         }
+        cw[0] = cw[1]; iw[0] = iw[1];
+        cw[1] = cw[2]; iw[1] = iw[2];
         // fold the lane's own 4 pixels first when they agree (the common case), else add them one by one
         int c0 = cls[0] < nc ? cls[0] : nc - 1;
         int i0 = ((thing_mask >> c0) & 1u) ? id[0] : 0;
@@ -1205,7 +1219,7 @@ extern "C" int emp_fuse_lut(const uint8_t *sem, const uint16_t *ids, int D, int 
         EMP_FAIL(EMP_ELAUNCH, "fuse: memset failed");
     int64_t HW = (int64_t)H * W;
     int gx = emp_grid(HW, 256, 1024);
-    const bool vec4 = fuse_vec4_ok(sem, ids, nullptr, W, up);
+    const bool vec4 = fuse_vec4_ok(sem, ids, nullptr, W, up) && HW < (1LL << 31);
     // ~8K pixels per block keeps the flush cheap; D * gh blocks fill the chip
     int gh = (int)emp_cdiv(HW, 8192);
     if ((int64_t)gh * D < 1024) gh = (int)emp_cdiv(1024, D);

@@ -14,6 +14,8 @@ tables; the result is identical to forward_matching + backward_matching + update
 slices (tests/test_pipeline_gpu.py).
 """
 import ctypes
+import functools
+import multiprocessing
 
 import numpy as np
 import torch
@@ -74,6 +76,51 @@ def _apply_matchers_now(rle_seg, matchers):
     return rle_seg
 
 
+def _end_of_stream(item):
+    """the sentinel the feeding loops put last: a string, or a tuple led by one (patterns.py:79-82, 316-318)"""
+    return isinstance(item, str) or (isinstance(item, tuple) and len(item) > 0 and isinstance(item[0], str))
+
+
+def _gpu_process_entry(fn):
+    """The reference starts its matcher with ``mp.Process(target=forward_matching, ...)`` from a process that already
+    holds the model on the GPU (scripts/pdl_inference3d.py:143-151) -- a FORK on Linux.  The reference's matcher is numpy;
+    this one needs the GPU, and a forked child of a process that has initialised HIP cannot use it.  In that case the entry
+    point starts a SPAWNED process (own interpreter, own HIP context) that runs the loop, and stays behind as a relay:
+    items of the caller's queue go on to the worker's queue (a fork-context queue cannot be handed to a spawned process:
+    its semaphores are unnamed), the worker's answer goes back through the caller's pipe.  The script runs unchanged; a
+    few seconds of start-up per plane and one more pickle per image.  Anywhere else (main process, thread, spawned
+    process) the function runs in place.  Arguments 1 and 3 are the queue and the pipe end (both entry points)."""
+    @functools.wraps(fn)
+    def entry(*args, **kwargs):
+        if not torch.cuda._is_in_bad_fork():
+            return fn(*args, **kwargs)
+        ctx = multiprocessing.get_context('spawn')
+        queue, matcher_in = args[1], args[3]
+        work_queue = ctx.Queue()
+        answer_out, answer_in = ctx.Pipe()
+        worker_args = list(args)
+        worker_args[1], worker_args[3] = work_queue, answer_in
+        proc = ctx.Process(target=entry, args=tuple(worker_args), kwargs=kwargs)
+        proc.start()
+        answer_in.close()
+        while True:
+            item = queue.get()
+            work_queue.put(item)
+            if _end_of_stream(item):
+                break
+        try:
+            answer = answer_out.recv()
+        except EOFError:
+            proc.join()
+            raise RuntimeError(f"{fn.__name__}: the spawned matcher process died (exit code {proc.exitcode})")
+        matcher_in.send(answer)
+        matcher_in.close()
+        proc.join()
+        return None
+    return entry
+
+
+@_gpu_process_entry
 def forward_matching(matchers, queue, rle_stack, matcher_in, labels, label_divisor, thing_list):
     """patterns.py:68-100 -- consumer loop of the matcher process (mp.Queue in, mp.Pipe out)."""
     while True:
@@ -206,6 +253,7 @@ def get_panoptic_seg(sem, instance_cells, label_divisor, thing_list, stuff_area=
     return merge_semantic_and_instance(sem, instance_seg, label_divisor, thing_list, stuff_area, void_label)
 
 
+@_gpu_process_entry
 def forward_multigpu(matchers, queue, rle_stack, matcher_in, confidence_thr, median_kernel_size, labels,
                      label_divisor, thing_list, stuff_area=32, void_label=0):
     """patterns.py:279-350 -- median queue + panoptic post-processing + RLE + forward matching on rank 0."""
