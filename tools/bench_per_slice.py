@@ -8,7 +8,7 @@ and the stack is evaluated once, in finish_tracking, by the whole-stack path (fo
 `script` = the reference script's PROCESS layout (scripts/pdl_inference3d.py:143-185): the main process runs the engine
 (graph) and puts every image, as a numpy array, into an mp.Queue; `forward_matching` runs in a forked mp.Process (which
 re-starts itself spawned, patterns._gpu_process_entry) and sends the matched stack back through a Pipe.
-usage: PYTHONPATH=. python tools/bench_per_slice.py [n_slices] [plain|tuned|graph|deferred|script] [S]"""
+usage: PYTHONPATH=. python tools/bench_per_slice.py [n_slices] [plain|tuned|graph|deferred|script|thread] [S]"""
 import os
 import sys
 import time
@@ -57,14 +57,14 @@ def main():
     mode = sys.argv[2] if len(sys.argv) > 2 else 'plain'            # plain | tuned | graph (= tuned + HIP graph)
     deferred = mode == 'deferred'
     B = 16 if deferred else 1
-    if mode in ('tuned', 'graph', 'deferred', 'script'):
+    if mode in ('tuned', 'graph', 'deferred', 'script', 'thread'):
         x1 = torch.rand((B, 1, S, S), device=dev).contiguous(memory_format=torch.channels_last)
         rep = tune_fused_convs(net, x1)
         counts = {}
         for best, _ in rep.values():
             counts[best] = counts.get(best, 0) + 1
         print(f'conv sites at batch {B}:', counts)
-    if mode in ('graph', 'deferred', 'script'):
+    if mode in ('graph', 'deferred', 'script', 'thread'):
         net = GraphedForward(net)
     model = PlantedModel(net, heads).eval()
     labels, thing, div = [1], bench.ENGINE['thing_list'], bench.ENGINE['label_divisor']
@@ -85,11 +85,19 @@ def main():
         torch.cuda.synchronize()
         t_all = time.perf_counter()
         stack = []
-        if mode == 'script':
+        if mode in ('script', 'thread'):
             import torch.multiprocessing as mp
-            queue = mp.Queue()
-            matcher_out, matcher_in = mp.Pipe()
-            proc = mp.Process(target=PA.forward_matching, args=(matchers, queue, [], matcher_in, labels, div, thing))
+            if mode == 'thread':                     # the same layout with ONE process on the GPU
+                import queue as _q
+                import threading
+                queue = _q.Queue()
+                matcher_out, matcher_in = mp.Pipe()
+                proc = threading.Thread(target=PA.forward_matching,
+                                        args=(matchers, queue, [], matcher_in, labels, div, thing))
+            else:
+                queue = mp.Queue()
+                matcher_out, matcher_in = mp.Pipe()
+                proc = mp.Process(target=PA.forward_matching, args=(matchers, queue, [], matcher_in, labels, div, thing))
             t0 = time.perf_counter()
             proc.start()
             tick('mp.Process(...).start(): fork of the process that holds the GPU', t0)
@@ -105,7 +113,7 @@ def main():
             stack = matcher_out.recv()[0]
             proc.join()
             tick('wait for the matcher process (its start-up included)', t0)
-        for t in range(D if mode != 'script' else 0):
+        for t in range(D if mode not in ('script', 'thread') else 0):
             t0 = time.perf_counter()
             pan = eng(images[t])
             tick('engine (forward + median + pixels)', t0)
@@ -118,7 +126,7 @@ def main():
             stack.append(PA.apply_matchers(seg, matchers))
             tick('forward matching', t0)
         t0 = time.perf_counter()
-        for pan in (eng.end() if mode != 'script' else []):
+        for pan in (eng.end() if mode not in ('script', 'thread') else []):
             seg = rle.pan_seg_to_rle_seg(pan.squeeze().cpu().numpy(), labels, div, thing, True)
             stack.append(PA.apply_matchers(seg, matchers))
         tick('engine.end + tail', t0)
