@@ -73,13 +73,14 @@ PMC_SOURCE = ('offline PMC ratio x algorithmic bytes (profiles/r3_pmc_bench_orth
               'WRITE_SIZE passes over this workload at --size 1024; the other dense kernels r2_pmc_bench_ortho512.md, '
               'the per-voxel kernels r1_pmc_postproc_256x512x512.md)')
 DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 'emp_conv_bn_act_nhwc',
+                 'emp_conv_splitk_bn_act_nhwc',
                  'emp_conv_bn_act_proj_nhwc', 'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
                  'emp_wino_output_transform', 'emp_wino4_input_transform', 'emp_wino4_output_transform',
                  'emp_wino3_input_transform', 'emp_wino3_output_transform',
                  'emp_pointwise_out_nhwc', 'emp_bn_relu_maxpool_nhwc', 'emp_slices_to_input', 'emp_gconv3x3_bn_act_nhwc',
                  'emp_stem_conv7_bn_relu_maxpool', 'emp_logits_to_prob', 'emp_pr_upsample2x', 'emp_pr_topk',
                  'emp_pr_point_sample', 'emp_pr_scatter')
-MFMA_KERNELS = ('emp_conv_bn_act_nhwc', 'emp_conv_bn_act_proj_nhwc', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
+MFMA_KERNELS = ('emp_conv_bn_act_nhwc', 'emp_conv_splitk_bn_act_nhwc', 'emp_conv_bn_act_proj_nhwc', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
                 'emp_gconv3x3_bn_act_nhwc')
 MFMA_F32_PEAK_TFLOPS = 157.3                   # dense fp32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)

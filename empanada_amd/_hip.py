@@ -44,6 +44,8 @@ SIGNATURES = {
     'emp_gconv_chunk': (_I, [_I]),
     'emp_gconv3x3_bn_act_nhwc': (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     'emp_conv_bn_act_nhwc': (_I, [_P, _P, _P, _P, _P, _L, _I] + [_I] * 10 + [_P, _L, _P]),
+    'emp_conv_splitk_plan': (_I, [_L, _I, _I, _I, _I]),
+    'emp_conv_splitk_bn_act_nhwc': (_I, [_P, _P, _P, _P, _P, _L, _I] + [_I] * 11 + [_P, _P, _L, _P]),
     'emp_wino_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     'emp_gemm_nt_batched': (_I, [_P, _P, _I, _L, _I, _I, _P, _P]),
     'emp_wino4_input_transform': (_I, [_P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
@@ -619,6 +621,44 @@ def conv_bn_act_nhwc(x, w_okkc, scale=None, shift=None, residual=None, relu=Fals
          residual.data_ptr() if residual is not None else None, rps, 2 if relu == 'gate' else int(bool(relu)),
          N, H, W, Cin, Cout, KH, KW,
          stride, pad, dil, out.data_ptr(), ops, stream(),
+         alg_bytes=4 * (x.numel() + w_okkc.numel() + N * Cout * OH * OW * (2 if residual is not None else 1)),
+         alg_flops=2 * N * OH * OW * Cout * Cin * KH * KW)
+    return out
+
+
+def conv_splitk_plan(M, Cout, Cin, KH, KW):
+    """number of K ranges emp_conv_splitk_bn_act_nhwc should use for this geometry (1: not worth splitting)"""
+    return int(load().emp_conv_splitk_plan(int(M), int(Cout), int(Cin), int(KH), int(KW)))
+
+
+def conv_splitk_bn_act_nhwc(x, w_okkc, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, dil=1, out=None,
+                            k_splits=None):
+    """conv_bn_act_nhwc for small launches: the reduction cut into k_splits ranges (emp_conv_splitk_bn_act_nhwc), partial
+    sums through a workspace, epilogue in the second pass.  k_splits=None asks emp_conv_splitk_plan."""
+    require_gpu()
+    N, Cin, H, W = x.shape
+    Cout, KH, KW, _ = w_okkc.shape
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    M = N * OH * OW
+    if k_splits is None:
+        k_splits = conv_splitk_plan(M, Cout, Cin, KH, KW)
+
+    def pixel_stride(t):
+        assert t.shape == (N, Cout, OH, OW) and t.dtype == torch.float32 and t.stride(1) == 1
+        ps = t.stride(3)
+        assert t.stride(2) == OW * ps and t.stride(0) == OH * OW * ps, "NHWC channel slice required"
+        return ps
+
+    if out is None:
+        out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    ops = pixel_stride(out)
+    rps = pixel_stride(residual) if residual is not None else 0
+    work = torch.empty((int(k_splits) * M * Cout,), dtype=torch.float32, device=x.device)
+    call('emp_conv_splitk_bn_act_nhwc', x.data_ptr(), _ptr(w_okkc), _ptr(scale), _ptr(shift),
+         residual.data_ptr() if residual is not None else None, rps, int(bool(relu)), N, H, W, Cin, Cout, KH, KW,
+         stride, pad, dil, int(k_splits), work.data_ptr(), out.data_ptr(), ops, stream(),
          alg_bytes=4 * (x.numel() + w_okkc.numel() + N * Cout * OH * OW * (2 if residual is not None else 1)),
          alg_flops=2 * N * OH * OW * Cout * Cin * KH * KW)
     return out

@@ -184,13 +184,20 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     const int cslabs = g.Cin / BK;
-    const int S = taps * cslabs;
+    // Split K (gridDim.z > 1, emp_conv_splitk_bn_act_nhwc): block z sums the slabs [s_lo, s_lo + S) of the taps x Cin / BK
+    // slabs of the reduction and writes its partial sums, through the identity epilogue, to plane z of a workspace
+    // (out + z * M * out_ps).  gridDim.z == 1: the whole reduction, as ever.
+    const int S_all = taps * cslabs;
+    const int s_lo = (int)((int64_t)S_all * blockIdx.z / gridDim.z);
+    const int S = (int)((int64_t)S_all * (blockIdx.z + 1) / gridDim.z) - s_lo;
+    const int tap0 = s_lo / cslabs, c00 = (s_lo - tap0 * cslabs) * BK;
+    if (gridDim.z > 1) g.out += (int64_t)blockIdx.z * g.M * g.out_ps;
     float4 ra[MODE == 0 ? AR : 16], rb[BROWS];
 
     // Staging state of the NEXT slab to load: filter tap, channel offset, and per A row the source pointer of the
     // tap (rows whose tap falls outside the image, or past M, read a dummy address and are zeroed after the load:
     // no divergent branches around the loads).  Pointers are recomputed once per tap, not per slab.
-    int ld_tap = 0, ld_c0 = 0;
+    int ld_tap = tap0, ld_c0 = c00;
     const float *a_ptr[AR];
     bool a_in[AR];
     auto set_tap = [&](int tap) {
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
             a_ptr[i] = a_in[i] ? g.x + (((int64_t)a_n[i] * g.H + iy) * g.W + ix) * g.Cin + lcol : g.x + lcol;
         }
     };
-    if constexpr (MODE == 0) set_tap(0);
+    if constexpr (MODE == 0) set_tap(tap0);
     auto load_slab = [&]() {
         if constexpr (MODE == 0) {
 #pragma unroll
@@ -300,11 +307,11 @@ __global__ __launch_bounds__(CG_THREADS, (BK == 16 ? 3 : 2)) void conv_igemm_f32
             const int cob = n0 + lrow + RPP * i;
             gb[i] = (cob < g.Cout) ? g.w + (int64_t)cob * taps * g.Cin + csw : cg_zero_page + csw;
         }
-        set_tap_g(0);
+        set_tap_g(tap0);
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)smem;
         const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(RPW * wave * BK * 4));
         const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((A_ELEMS + RPW * wave * BK) * 4));
-        int gl_tap = 0, gl_c0 = 0;
+        int gl_tap = tap0, gl_c0 = c00;
         auto issue_slab = [&](int ring) {
 #pragma unroll
             for (int i = 0; i < AR; ++i)
@@ -664,6 +671,116 @@ extern "C" int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const f
 #undef CG_GO
 #undef CG_GATE
     EMP_CHECK_LAUNCH("emp_conv_bn_act_nhwc");
+    return EMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-K form for SMALL launches (a 512^2 tile at batch 1 leaves layer3 / layer4 / ASPP with 8-64 tiles of 128 pixels
+// on 256 CUs: profiles/r3_batch1_forward_512.md).  The reduction is cut into k_splits ranges of whole 32-channel slabs,
+// every range is a block of its own (gridDim.z) that writes its partial sums to a workspace, and a second pass adds the
+// partials in ascending order and applies the epilogue:
+//   out = relu?((((p_0 + p_1) + p_2) + ...) * scale + shift (+ residual)),  p_z = the fmaf chain of emp_conv_bn_act_nhwc
+//   (K-slab 32) over slabs [S z / k, S (z + 1) / k) of the S = KH KW Cin / 32 slabs, from +0.
+// Deterministic (no atomics); oracle/dense.py::conv_bn_act_nhwc(slab=32, k_splits=k) restates it.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ work, int nz, int64_t M, int Cout,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ shift,
+                                                            const float *__restrict__ res, int64_t res_ps, int relu,
+                                                            float *__restrict__ out, int64_t out_ps)
+{
+    const int C4 = Cout >> 2;
+    const int64_t total = M * C4, plane = M * (int64_t)Cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / C4;
+        const int co = (int)(i - p * C4) * 4;
+        const float *w = work + p * Cout + co;
+        float4 t = *reinterpret_cast<const float4 *>(w);
+        for (int z = 1; z < nz; ++z) {
+            const float4 u = *reinterpret_cast<const float4 *>(w + z * plane);
+            t.x = __fadd_rn(t.x, u.x); t.y = __fadd_rn(t.y, u.y); t.z = __fadd_rn(t.z, u.z); t.w = __fadd_rn(t.w, u.w);
+        }
+        float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sc = scale ? scale[co + e] : 1.f, sh = shift ? shift[co + e] : 0.f;
+            v[e] = __fadd_rn(__fmul_rn(v[e], sc), sh);
+        }
+        if (res) {
+            const float4 r4 = *reinterpret_cast<const float4 *>(res + p * res_ps + co);
+            v[0] = __fadd_rn(v[0], r4.x); v[1] = __fadd_rn(v[1], r4.y); v[2] = __fadd_rn(v[2], r4.z); v[3] = __fadd_rn(v[3], r4.w);
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<float4 *>(out + p * out_ps + co) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// how many ranges a launch of this geometry should be cut into (1: it fills the chip as it is, or cannot be cut)
+extern "C" int emp_conv_splitk_plan(int64_t M, int Cout, int Cin, int KH, int KW)
+{
+    if (M <= 0 || Cout <= 0 || Cin % 32 != 0 || Cout % 4 != 0) return 1;
+    const CgPlan pl = cg_plan(M, Cout, 1, false, true, true, Cin);
+    const int64_t tiles = (int64_t)pl.tiles_m * pl.tiles_n;
+    const int S = KH * KW * (Cin / 32);
+    // A block's life is ~6 us of prologue + epilogue plus 0.85 us of matrix work per slab (one wave per SIMD, two
+    // accumulator chains: the matrix pipe of its CU is busy), so the launch is as fast as its LONGEST ROUND of blocks:
+    // cut until the blocks just fill the 256 CUs once (tiles 32, S 72: 8 ranges, 256 blocks, 14 us; 10 ranges -- 320
+    // blocks, two rounds -- measured 25 us)
+    if (tiles > 128) return 1;
+    int64_t k = 256 / tiles;
+    if (k > S / 4) k = S / 4;                       // at least four slabs per range
+    if (k > 32) k = 32;
+    return k >= 2 ? (int)k : 1;
+}
+
+extern "C" int emp_conv_splitk_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
+                                           const float *residual, int64_t res_pixel_stride, int relu, int N, int H, int W,
+                                           int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int k_splits,
+                                           float *work, float *out, int64_t out_pixel_stride, void *stream)
+{
+    EMP_REQUIRE(x && w_okkc && out && work, "conv_splitk: null pointer");
+    EMP_REQUIRE(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_splitk: bad shape");
+    EMP_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0, "conv_splitk: Cin %d must be a multiple of 32, Cout %d of 4", Cin, Cout);
+    EMP_REQUIRE(relu == 0 || relu == 1, "conv_splitk: relu must be 0 or 1");
+    EMP_REQUIRE(KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7 && stride >= 1 && dil >= 1 && pad >= 0, "conv_splitk: bad filter geometry");
+    const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+    const int OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    EMP_REQUIRE(OH > 0 && OW > 0, "conv_splitk: empty output");
+    const int S = KH * KW * (Cin / 32);
+    EMP_REQUIRE(k_splits >= 1 && k_splits <= S && k_splits <= 64, "conv_splitk: k_splits %d not in 1..min(%d, 64)", k_splits, S);
+    if (out_pixel_stride == 0) out_pixel_stride = Cout;
+    if (res_pixel_stride == 0) res_pixel_stride = Cout;
+    EMP_REQUIRE(out_pixel_stride >= Cout && res_pixel_stride >= Cout, "conv_splitk: bad pixel stride");
+    EMP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_okkc) | reinterpret_cast<uintptr_t>(work) |
+                  reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(scale) |
+                  reinterpret_cast<uintptr_t>(shift)) & 15) == 0 && (out_pixel_stride & 3) == 0 && (res_pixel_stride & 3) == 0,
+                "conv_splitk: pointers must be 16-byte aligned, pixel strides multiples of 4");
+    EMP_REQUIRE(out != x && work != x && work != out, "conv_splitk: buffers must not alias");
+    if (N == 0) return EMP_OK;
+    ConvGeom g;
+    g.x = x; g.w = w_okkc; g.scale = nullptr; g.shift = nullptr; g.res = nullptr; g.out = work;
+    g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.KH = KH; g.KW = KW;
+    g.stride = stride; g.pad = pad; g.dil = dil; g.relu = 0;
+    g.M = (int64_t)N * OH * OW; g.out_ps = Cout; g.res_ps = Cout;
+    g.x_bs = g.w_bs = g.out_bs = 0; g.tiles = nullptr; g.proj_w = nullptr; g.proj_out = nullptr; g.proj_n = 0; g.hw = 1;
+    const CgPlan pl = cg_plan(g.M, Cout, 1, false, true, true, Cin);
+    EMP_REQUIRE((int64_t)pl.tiles_m * pl.tiles_n < (1LL << 28), "conv_splitk: too many tiles");
+    g.tiles_m = pl.tiles_m;
+    g.tiles_n = pl.tiles_n;
+    const int T = g.tiles_m * g.tiles_n;
+    const dim3 grid(8 * ((T + 7) / 8), 1, k_splits);
+    hipStream_t st = emp_stream(stream);
+    if (pl.narrow)
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 0, false, 32, false, true>), grid, dim3(CG_THREADS), 0, st, g);
+    else
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 0, false, 32, false, true>), grid, dim3(CG_THREADS), 0, st, g);
+    EMP_CHECK_LAUNCH("emp_conv_splitk_bn_act_nhwc(partials)");
+    const int64_t total = g.M * (Cout / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(emp_grid(total, 256, 4096)), dim3(256), 0, st, work, k_splits, g.M, Cout,
+                       scale, shift, residual, res_pixel_stride, relu, out, out_pixel_stride);
+    EMP_CHECK_LAUNCH("emp_conv_splitk_bn_act_nhwc(reduce)");
     return EMP_OK;
 }
 

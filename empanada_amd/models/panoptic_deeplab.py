@@ -142,6 +142,9 @@ class FusedConvBNAct(nn.Module):
     """Conv2d + FusedBNAct (+ residual) as one call with three interchangeable implementations:
       'miopen' : MIOpen convolution, then the emp_bn_act_nhwc epilogue pass              (default)
       'direct' : emp_conv_bn_act_nhwc -- implicit GEMM on the fp32 matrix cores, epilogue fused
+      'direct_sk': emp_conv_splitk_bn_act_nhwc -- the same kernel with the reduction cut into ranges, one block per
+                 range, for launches that would leave most CUs without a block (one 512^2 tile at batch 1: layer3 /
+                 layer4 / ASPP); a candidate only where emp_conv_splitk_plan says so
       'wino'   : Winograd F(2x2,3x3), input transform inside the GEMM loader -- emp_wino_gemm_fused /
                  emp_wino_output_transform
       'wino4'  : Winograd F(4x4,3x3), 36 GEMMs, 4x fewer matrix-core FLOPs; rounding error about 10x the direct
@@ -165,7 +168,8 @@ class FusedConvBNAct(nn.Module):
         self._U3 = None
         self._tiles = {}
 
-    def candidates(self, has_residual):
+    def candidates(self, has_residual, shape=None):
+        """shape: the (N, Cin, H, W) the site is called with -- lets the small-launch form in when it applies"""
         c = self.conv
         out = ['miopen']
         square = (c.bias is None and c.padding_mode == 'zeros' and c.kernel_size[0] == c.kernel_size[1]
@@ -173,6 +177,13 @@ class FusedConvBNAct(nn.Module):
                   and c.weight.dtype == torch.float32)
         if square and c.groups == 1 and c.in_channels % 16 == 0:
             out.append('direct')
+            if shape is not None and c.in_channels % 32 == 0 and c.out_channels % 4 == 0 and self.bn.relu in (0, 1, False, True):
+                from .. import _hip
+                k, st, pd, dl = c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0]
+                oh = (shape[2] + 2 * pd - dl * (k - 1) - 1) // st + 1
+                ow = (shape[3] + 2 * pd - dl * (k - 1) - 1) // st + 1
+                if _hip.conv_splitk_plan(shape[0] * oh * ow, c.out_channels, c.in_channels, k, k) > 1:
+                    out.append('direct_sk')
             if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == c.dilation and c.out_channels % 4 == 0
                     and c.in_channels % 32 == 0 and not has_residual):
                 out.extend(['wino', 'wino_sep', 'wino4', 'wino3'])
@@ -184,7 +195,7 @@ class FusedConvBNAct(nn.Module):
 
     def _prepare(self, impl):
         from .. import _hip
-        if impl in ('direct', 'grouped') and self._w_okkc is None:
+        if impl in ('direct', 'direct_sk', 'grouped') and self._w_okkc is None:
             self._w_okkc = self.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
         if impl in ('wino', 'wino_sep') and self._U is None:
             self._U = _hip.wino_filter_transform(self.conv.weight.detach())
@@ -194,7 +205,7 @@ class FusedConvBNAct(nn.Module):
             self._U3 = _hip.wino3_filter_transform(self.conv.weight.detach()).to(self.conv.weight.device)
 
     def release(self, keep):
-        if keep not in ('direct', 'grouped'):
+        if keep not in ('direct', 'direct_sk', 'grouped'):
             self._w_okkc = None
         if keep not in ('wino', 'wino_sep'):
             self._U = None
@@ -215,9 +226,17 @@ class FusedConvBNAct(nn.Module):
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         self._prepare(impl)
-        if impl == 'direct':
+        if impl in ('direct', 'direct_sk'):
             if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
                 residual = residual.contiguous(memory_format=torch.channels_last)
+            if impl == 'direct_sk':
+                oh = (x.shape[2] + 2 * c.padding[0] - c.dilation[0] * (c.kernel_size[0] - 1) - 1) // c.stride[0] + 1
+                ow = (x.shape[3] + 2 * c.padding[0] - c.dilation[0] * (c.kernel_size[0] - 1) - 1) // c.stride[0] + 1
+                ks = _hip.conv_splitk_plan(x.shape[0] * oh * ow, c.out_channels, c.in_channels, *c.kernel_size)
+                if ks > 1:                 # a bigger batch than the one the site was tuned on fills the chip: plain form
+                    return _hip.conv_splitk_bn_act_nhwc(x, self._w_okkc, self.bn.scale, self.bn.shift, residual,
+                                                        self.bn.relu, c.stride[0], c.padding[0], c.dilation[0], out,
+                                                        k_splits=ks)
             return _hip.conv_bn_act_nhwc(x, self._w_okkc, self.bn.scale, self.bn.shift, residual, self.bn.relu,
                                          c.stride[0], c.padding[0], c.dilation[0], out)
         assert residual is None
@@ -785,8 +804,8 @@ def tune_fused_convs(model, example, reps=5, verbose=False, allow=None, model_ar
         m.impl = 'miopen'
         res = torch.randn_like(m(x)) if has_res else None
         times = {}
-        for impl in m.candidates(has_res):
-            if allow is not None and impl not in allow and impl != 'miopen':
+        for impl in m.candidates(has_res, shape):
+            if allow is not None and impl not in allow and impl != 'miopen' and not (impl == 'direct_sk' and 'direct' in allow):
                 continue
             m.impl = impl
             for _ in range(2):

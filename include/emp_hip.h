@@ -126,6 +126,19 @@ int emp_conv_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale
                          const float *residual, int64_t res_pixel_stride, int relu, int N, int H, int W,
                          int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float *out,
                          int64_t out_pixel_stride, void *stream);
+/* D4c: the same convolution for SMALL launches (one 512^2 tile at batch 1: layer3 / layer4 / ASPP have 8-64 tiles of 128
+ * pixels for 256 CUs) -- the per-slice protocol's forward, empanada/inference/engines.py:141-159 one image per call.
+ * The reduction over the S = KH KW Cin / 32 slabs of 32 channels is cut into k_splits ranges [S z / k, S (z + 1) / k);
+ * every range is a block of its own and writes its partial sums (the fmaf chain of emp_conv_bn_act_nhwc with K-slab 32,
+ * from +0) to plane z of `work` (k_splits x N*OH*OW x Cout floats); a second pass adds the planes in ascending order
+ * and applies the epilogue, out = relu?(sum * scale + shift (+ residual)), every operation a separate fp32 rounding.
+ * Deterministic.  Cin % 32 == 0, Cout % 4 == 0, relu 0 / 1; all pointers 16-byte aligned, pixel strides % 4 == 0.
+ * emp_conv_splitk_plan: the number of ranges worth using for a geometry (1 = the launch fills the chip as it is). */
+int emp_conv_splitk_plan(int64_t M, int Cout, int Cin, int KH, int KW);
+int emp_conv_splitk_bn_act_nhwc(const float *x, const float *w_okkc, const float *scale, const float *shift,
+                                const float *residual, int64_t res_pixel_stride, int relu, int N, int H, int W,
+                                int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int k_splits,
+                                float *work, float *out, int64_t out_pixel_stride, void *stream);
 
 /* D4 + D6 in one launch: the convolution's epilogue also evaluates a following 1x1 convolution to proj_n <= 4
  * channels (head = separable conv -> BN -> ReLU -> Conv2d(256, n, 1): heads.py:9-19), so the 256-channel activation

@@ -46,6 +46,8 @@ def lib():
         L.emp_oracle_dwconv_nhwc.argtypes = [f32p, f32p, f32p] + [ctypes.c_int] * 5 + [f32p]
         L.emp_oracle_conv_bn_act_nhwc.restype = None
         L.emp_oracle_conv_bn_act_nhwc.argtypes = [f32p] * 5 + [ctypes.c_int] * 12 + [f32p]
+        L.emp_oracle_conv_splitk_bn_act_nhwc.restype = None
+        L.emp_oracle_conv_splitk_bn_act_nhwc.argtypes = [f32p] * 5 + [ctypes.c_int] * 12 + [f32p]
         L.emp_oracle_conv7s2_c1.restype = None
         L.emp_oracle_conv7s2_c1.argtypes = [f32p, f32p] + [ctypes.c_int] * 4 + [f32p]
         L.emp_oracle_gconv3x3_bn_act_nhwc.restype = None

@@ -259,6 +259,51 @@ void emp_oracle_conv_bn_act_nhwc(const float *x, const float *w, const float *sc
             }
 }
 
+/* D4c (emp_conv_splitk_bn_act_nhwc): the same convolution with the reduction cut into k_splits ranges of whole
+ * 32-channel slabs.  Slab index s = tap * (Cin / 32) + c0 / 32 runs over S = KH KW Cin / 32 slabs; range z covers
+ * [S z / k, S (z + 1) / k); partial p_z = the fmaf chain of the function above over its slabs, from +0; the result is
+ * ((p_0 + p_1) + p_2) + ... then * scale, + shift, + residual, relu -- every step a separate fp32 rounding. */
+void emp_oracle_conv_splitk_bn_act_nhwc(const float *x, const float *w, const float *scale, const float *shift,
+                                        const float *res, int relu, int N, int H, int W, int Cin, int Cout, int KH,
+                                        int KW, int stride, int pad, int dil, int k_splits, float *out)
+{
+    const int slab = 32;
+    const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+    const int OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    const int cslabs = Cin / slab, S = KH * KW * cslabs;
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox) {
+                const int64_t p = ((int64_t)n * OH + oy) * OW + ox;
+                for (int co = 0; co < Cout; ++co) {
+                    float total = 0.0f;
+                    for (int z = 0; z < k_splits; ++z) {
+                        const int s_lo = (int)((int64_t)S * z / k_splits), s_hi = (int)((int64_t)S * (z + 1) / k_splits);
+                        float acc = 0.0f;
+                        for (int s = s_lo; s < s_hi; ++s) {
+                            const int tap = s / cslabs, c0 = (s % cslabs) * slab;
+                            const int ky = tap / KW, kx = tap % KW;
+                            const int iy = oy * stride - pad + ky * dil, ix = ox * stride - pad + kx * dil;
+                            const int in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                            const float *xp = in ? x + (((int64_t)n * H + iy) * W + ix) * Cin : 0;
+                            const float *wp = w + (((int64_t)co * KH + ky) * KW + kx) * Cin;
+                            for (int j = 0; j < slab / 2; ++j) {
+                                acc = fmaf(in ? xp[c0 + j] : 0.0f, wp[c0 + j], acc);
+                                acc = fmaf(in ? xp[c0 + slab / 2 + j] : 0.0f, wp[c0 + slab / 2 + j], acc);
+                            }
+                        }
+                        total = z == 0 ? acc : total + acc;
+                    }
+                    float v = total;
+                    v = v * (scale ? scale[co] : 1.0f);
+                    v = v + (shift ? shift[co] : 0.0f);
+                    if (res) v = v + res[p * Cout + co];
+                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    out[p * Cout + co] = v;
+                }
+            }
+}
+
 /* D8 (emp_gconv3x3_bn_act_nhwc): grouped 3x3 convolution, padding 1, stride 1 or 2, NHWC, G groups of GW channels
  * (Conv2d(w, w, 3, stride, 1, groups=G) of the RegNet bottleneck, empanada/models/encoders/regnet.py:59-71) + affine +
  * ReLU.  w: (G*GW, 3, 3, GW).  One fmaf chain from +0 per output: taps in raster order; per tap chunks of CK channels

@@ -85,6 +85,26 @@ def conv_bn_act_nhwc(x_nhwc, w_okkc, scale=None, shift=None, residual=None, relu
     return y
 
 
+def conv_splitk_bn_act_nhwc(x_nhwc, w_okkc, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, dil=1,
+                            k_splits=2):
+    """The split-K form of the convolution above (include/emp_hip.h, D4c: emp_conv_splitk_bn_act_nhwc): partial fmaf
+    chains over k_splits ranges of 32-channel slabs, added in ascending order, then the epilogue.  Plain C."""
+    x = np.ascontiguousarray(x_nhwc, dtype=np.float32)
+    w = np.ascontiguousarray(w_okkc, dtype=np.float32)
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    y = np.empty((N, OH, OW, Cout), dtype=np.float32)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    keep = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (scale, shift, residual)]
+    ptrs = [None if a is None else a.ctypes.data_as(f32p) for a in keep]
+    lib().emp_oracle_conv_splitk_bn_act_nhwc(x.ctypes.data_as(f32p), w.ctypes.data_as(f32p), ptrs[0], ptrs[1], ptrs[2],
+                                             int(bool(relu)), N, H, W, Cin, Cout, KH, KW, stride, pad, dil,
+                                             int(k_splits), y.ctypes.data_as(f32p))
+    return y
+
+
 def gconv_chunk(group_w):
     """channels per K chunk of the grouped kernel (emp_gconv_chunk)"""
     return 24 if group_w % 24 == 0 else 16 if group_w % 16 == 0 else 8

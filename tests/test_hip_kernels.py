@@ -596,6 +596,61 @@ def test_conv_bn_act_nhwc(hip, cfg):
 
 
 @pytest.mark.parametrize('cfg', [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, residual, relu, affine, k_splits (None = emp_conv_splitk_plan)
+    (1, 32, 32, 256, 256, 3, 1, 1, 1, False, True, True, None),     # layer3 conv2 of a 512^2 tile: 32 tiles -> 8 ranges
+    (1, 32, 32, 1024, 256, 1, 1, 0, 1, False, True, True, None),    # layer3 conv1
+    (1, 32, 32, 256, 1024, 1, 1, 0, 1, True, True, True, 3),        # conv3 + identity
+    (1, 16, 24, 64, 48, 3, 2, 1, 1, False, False, False, 2),        # stride 2, no affine, narrow tile, ragged M
+    (2, 9, 7, 96, 132, 3, 1, 2, 2, True, True, True, 5),            # dilation, couts past the last tile
+    (1, 8, 8, 32, 64, 1, 1, 0, 1, False, False, True, 1),           # one range = the unsplit summation with K-slab 32
+])
+def test_conv_splitk_bn_act_nhwc(hip, cfg):
+    """emp_conv_splitk_bn_act_nhwc (D4c, small launches): bit-exact against the C oracle (partial fmaf chains per K
+    range, added in ascending order, separate roundings in the epilogue); deterministic from run to run; within fp32
+    rounding of torch's conv2d + affine + residual + relu: |err| <= 2e-6 * sum|x||w| * |scale| + 1e-6."""
+    from oracle import dense as OD
+    N, H, W, Cin, Cout, k, stride, pad, dil, use_res, relu, affine, ks = cfg
+    g = torch.Generator().manual_seed(Cin * 5 + Cout + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k) ** 0.5)
+    sc = torch.rand(Cout, generator=g) + 0.5 if affine else None
+    sh = torch.randn(Cout, generator=g) if affine else None
+    ref = torch.nn.functional.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    w_okkc = w.permute(0, 2, 3, 1).contiguous()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    resd = res.cuda().contiguous(memory_format=torch.channels_last) if use_res else None
+    M = ref.shape[0] * ref.shape[2] * ref.shape[3]
+    if ks is None:
+        ks = hip.conv_splitk_plan(M, Cout, Cin, k, k)
+        assert ks >= 2
+    args = (xd, w_okkc.cuda(), sc.cuda() if affine else None, sh.cuda() if affine else None, resd, relu, stride, pad, dil)
+    got = hip.conv_splitk_bn_act_nhwc(*args, k_splits=ks)
+    assert torch.equal(got, hip.conv_splitk_bn_act_nhwc(*args, k_splits=ks))
+    exp = OD.conv_splitk_bn_act_nhwc(x.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), sc.numpy() if affine else None,
+                                     sh.numpy() if affine else None,
+                                     res.permute(0, 2, 3, 1).numpy() if use_res else None, relu, stride, pad, dil, ks)
+    np.testing.assert_array_equal(got.permute(0, 2, 3, 1).cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    if ks == 1:                            # one range: the plain kernel's sum whenever that runs with K-slab 32
+        plain = OD.conv_bn_act_nhwc(x.permute(0, 2, 3, 1).numpy(), w_okkc.numpy(), sc.numpy() if affine else None,
+                                    sh.numpy() if affine else None, None, relu, stride, pad, dil, slab=32)
+        np.testing.assert_array_equal(exp.view(np.uint32), plain.view(np.uint32))
+    bound = torch.nn.functional.conv2d(x.abs(), w.abs(), None, stride=stride, padding=pad, dilation=dil)
+    y = ref
+    if affine:
+        y = y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        bound = bound * sc.view(1, -1, 1, 1)
+    if use_res:
+        y = y + res
+    if relu:
+        y = torch.relu(y)
+    assert torch.all((got.cpu() - y).abs() <= 2e-6 * bound + 1e-6)
+    buf = torch.full((N, Cout + 8, ref.shape[2], ref.shape[3]), 5.0, device='cuda').contiguous(memory_format=torch.channels_last)
+    hip.conv_splitk_bn_act_nhwc(*args, out=buf[:, 8:], k_splits=ks)
+    assert torch.equal(buf[:, 8:], got) and torch.all(buf[:, :8] == 5.0)
+
+
+@pytest.mark.parametrize('cfg', [
     (2, 9, 11, 2, 72, 1, True),        # RegNetY-6.4GF stage 1: 2 groups of 72, chunks of 24 channels
     (1, 16, 16, 4, 72, 2, True),       # stride 2 (first block of a stage)
     (3, 7, 5, 18, 72, 1, False),       # 18 groups (stage 4 width 1296), no ReLU
