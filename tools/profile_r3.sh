@@ -33,6 +33,25 @@ mitonet)
     > $R/gpurun_out/r3_prof_mitonet.log 2>&1 || exit 1
   python3 $R/tools/prof_summary.py /tmp/prof_mito/*/*_kernel_trace.csv 2 > $R/gpurun_out/r3_bench_ortho1024_mitonet_pr_timed_region.md
   ;;
+final)
+  # the round's closing evidence: default bench (tuner choices saved), rocprofv3 kernel trace of the same command with the
+  # choices replayed -> timed-region summary, the post-processing in isolation, the per-slice protocol lines
+  cd $R
+  timeout -k 10 900 python bench.py --steps 5 --warmup 1 --save-tune gpurun_out/r3_tune_choices_ortho1024.json \
+    > gpurun_out/r3_bench_ortho1024.json 2> gpurun_out/r3_bench_ortho1024.log || exit 1
+  tail -1 gpurun_out/r3_bench_ortho1024.log
+  cd /tmp
+  timeout -k 10 700 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pdl -- \
+    python3 $R/bench.py --steps 2 --warmup 1 --load-tune $R/gpurun_out/r3_tune_choices_ortho1024.json --no-cpu-baseline \
+    --no-forward-check > $R/gpurun_out/r3_prof_pdl.log 2>&1 || exit 1
+  python3 $R/tools/prof_summary.py /tmp/prof_pdl/*/*_kernel_trace.csv 2 > $R/gpurun_out/r3_bench_ortho1024_timed_region.md
+  cp /tmp/prof_pdl/*/*_kernel_stats.csv $R/gpurun_out/r3_bench_ortho1024_kernel_stats_full_run.csv
+  rm -rf /tmp/prof_pdl
+  cd $R
+  python tools/postproc_isolated.py 1024 > gpurun_out/r3_postproc_isolated_1024.md 2>/dev/null
+  for m in graph thread deferred; do python tools/bench_per_slice.py 256 $m 2>/dev/null | grep -v amdgpu.ids; done \
+    > gpurun_out/r3_per_slice_protocol_final.txt
+  ;;
 esac
 done
 echo all done
