@@ -431,7 +431,14 @@ class _ASPPPooling(nn.Module):
             if getattr(self, '_w_okkc', None) is None or self._w_okkc.device != x.device:
                 self._w_okkc = conv.weight.detach().permute(0, 2, 3, 1).contiguous()
             pooled = x.mean(dim=(2, 3), keepdim=True).contiguous(memory_format=torch.channels_last)
-            y = _hip.conv_bn_act_nhwc(pooled, self._w_okkc, relu=True)
+            # N pixels x 2048 channels -> 256: four tiles whose blocks would each walk all 64 K-slabs (73 us); cut into
+            # ranges it is one short round of blocks (deterministic too: partial sums added in a fixed order)
+            ks = _hip.conv_splitk_plan(pooled.shape[0], conv.out_channels, conv.in_channels, 1, 1) \
+                if conv.in_channels % 32 == 0 and conv.out_channels % 4 == 0 else 1
+            if ks > 1:
+                y = _hip.conv_splitk_bn_act_nhwc(pooled, self._w_okkc, relu=True, k_splits=ks)
+            else:
+                y = _hip.conv_bn_act_nhwc(pooled, self._w_okkc, relu=True)
             return _up_bilinear(y, size, True, out)
         return _up_bilinear(self.aspp_pooling(x), size, self.hip_ops, out)
 

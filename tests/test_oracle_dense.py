@@ -34,6 +34,27 @@ def test_conv_oracle_vs_torch(cfg, slab):
     assert np.all(np.abs(got - _nhwc(exp)) <= 2e-6 * _nhwc(bound) + 1e-6)
 
 
+@pytest.mark.parametrize('cfg', [(1, 9, 7, 64, 24, 3, 1, 1, 1, 5), (2, 6, 6, 96, 20, 1, 1, 0, 1, 3),
+                                 (1, 11, 8, 32, 12, 3, 2, 2, 2, 4)])
+def test_conv_splitk_oracle_vs_torch(cfg):
+    """D4c: partial chains per K range added in ascending order -- within fp32 rounding of torch's conv2d, and with ONE
+    range exactly the plain oracle with a K-slab of 32"""
+    N, H, W, Cin, Cout, k, stride, pad, dil, ks = cfg
+    g = torch.Generator().manual_seed(Cin + Cout + k + ks)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, None, stride, pad, dil)
+    res = torch.randn(ref.shape, generator=g)
+    got = OD.conv_splitk_bn_act_nhwc(_nhwc(x), _nhwc(w), sc.numpy(), sh.numpy(), _nhwc(res), True, stride, pad, dil, ks)
+    exp = torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    bound = F.conv2d(x.abs(), w.abs(), None, stride, pad, dil) * sc.view(1, -1, 1, 1)
+    assert np.all(np.abs(got - _nhwc(exp)) <= 2e-6 * _nhwc(bound) + 1e-6)
+    one = OD.conv_splitk_bn_act_nhwc(_nhwc(x), _nhwc(w), sc.numpy(), sh.numpy(), _nhwc(res), True, stride, pad, dil, 1)
+    plain = OD.conv_bn_act_nhwc(_nhwc(x), _nhwc(w), sc.numpy(), sh.numpy(), _nhwc(res), True, stride, pad, dil, 32)
+    np.testing.assert_array_equal(one.view(np.uint32), plain.view(np.uint32))
+
+
 @pytest.mark.parametrize('m,tol', [(2, 1e-5), (3, 2e-5), (4, 2e-5)])
 @pytest.mark.parametrize('dil', [1, 2, 6])
 def test_winograd_oracles_vs_torch(m, tol, dil):
