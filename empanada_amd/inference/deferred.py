@@ -32,16 +32,33 @@ _PAN_OPS = ('squeeze', 'cpu', 'numpy', 'detach', 'contiguous')
 
 
 class _Pending:
-    """what a matcher's ``target_rle`` holds while its slices are deferred (not None: the matcher is initialised)"""
+    """what a matcher's ``target_rle`` holds while its slices are deferred (not None: the matcher is initialised).
+    Pickling the matcher (it may cross an mp.Queue) files the recorded calls first and stores the real target."""
 
-    def __init__(self, session, stage):
-        self.session, self.stage = session, stage
+    def __init__(self, session, stage, owner=None):
+        self.session, self.stage, self.owner = session, stage, owner
+
+    def resolve(self):
+        """file the recorded calls: afterwards the owning matcher holds its real target and label counter"""
+        if self.stage == 'fwd':
+            self.session._forward_now()
+        else:
+            self.session._backward_now()
+
+    def __reduce__(self):
+        self.resolve()
+        real = self.owner.target_rle if self.owner is not None else None
+        return (_same, (None if isinstance(real, _Pending) else real,))
 
     def _die(self, *a, **k):
         raise RuntimeError("this matcher's target belongs to a deferred stack; use the matcher through "
                            "apply_matchers / backward_matching or build the engine with deferred=False")
 
     keys = items = values = __iter__ = __len__ = __getitem__ = _die
+
+
+def _same(x):
+    return x
 
 
 class StackSession:
@@ -59,6 +76,7 @@ class StackSession:
         self.uniform = True
         self.n_fwd = 0
         self.chunks = []                       # (first call, end call, {head: (n, ...) fp32 tensor})
+        self.chunk_of = []                     # call -> index into chunks
         # replay cursor of the per-slice engine code (uses the engine's own median queue)
         self.eager_fed = 0
         self.eager_out = []
@@ -121,19 +139,18 @@ class StackSession:
                 raise RuntimeError(f"deferred engine: the model returned {heads[short[0]].size(0)} slices of "
                                    f"'{short[0]}' for a batch of {hi - self.n_fwd} images -- a model that answers one "
                                    f"image per call needs deferred_batch=1 (or deferred=False)")
+            self.chunk_of += [len(self.chunks)] * (hi - self.n_fwd)
             self.chunks.append((self.n_fwd, hi, {k: heads[k].float() for k in _HEADS}))
             for i in range(self.n_fwd, hi):
                 self.images[i] = None
             self.n_fwd = hi
 
     def _head_slice(self, t):
-        for lo, hi, heads in reversed(self.chunks):
-            if lo <= t < hi:
-                out = {k: heads[k][t - lo:t - lo + 1] for k in _HEADS}
-                if self.sizes[t] is not None:
-                    out['size'] = self.sizes[t]
-                return out
-        raise IndexError(t)
+        lo, _, heads = self.chunks[self.chunk_of[t]]
+        out = {k: heads[k][t - lo:t - lo + 1] for k in _HEADS}
+        if self.sizes[t] is not None:
+            out['size'] = self.sizes[t]
+        return out
 
     # ------------------------------------------------------------------ values on demand (replay of the per-slice code)
     def force_pan(self, k):
@@ -230,12 +247,13 @@ class StackSession:
             things = set(self.rle_args[2]) & set(self.rle_args[0])
             ok = (all(type(mt) is RLEMatcher and mt.target_rle is None and mt.assign_new for mt in matchers)
                   and sorted(mt.class_id for mt in matchers) == sorted(things)
+                  and all(mt.label_divisor == self.rle_args[1] for mt in matchers)
                   and len({(mt.merge_iou_thr, mt.merge_ioa_thr) for mt in matchers}) <= 1)
             if ok:
                 self.matchers = matchers
                 self.matcher_init = [(mt.next_label, mt.assign_new) for mt in matchers]
                 for mt in matchers:
-                    mt.target_rle = _Pending(self, 'fwd')
+                    mt.target_rle = _Pending(self, 'fwd', mt)
         elif ok:
             ok = len(matchers) == len(self.matchers) and all(a is b for a, b in zip(matchers, self.matchers)) and all(
                 isinstance(mt.target_rle, _Pending) and mt.target_rle.session is self for mt in matchers)
@@ -265,7 +283,7 @@ class StackSession:
         if ok:
             self.bwd = 'lazy'
             for mt in self.matchers:
-                mt.target_rle, mt.assign_new = _Pending(self, 'bwd'), False
+                mt.target_rle, mt.assign_new = _Pending(self, 'bwd', mt), False
         return ok
 
     # ------------------------------------------------------------------ whole-stack evaluation
@@ -358,10 +376,9 @@ class LazyPan:
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
         unwrap = lambda x: x._force() if isinstance(x, LazyPan) else x
-        args = tuple(unwrap(a) for a in args)
-        kwargs = {k: unwrap(v) for k, v in (kwargs or {}).items()}
-        return func(*args, **kwargs)
+        return func(*tree_map(unwrap, tuple(args)), **tree_map(unwrap, dict(kwargs or {})))
 
     def __reduce__(self):
         v = self._force()

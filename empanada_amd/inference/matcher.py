@@ -11,6 +11,7 @@ import numpy as np
 from scipy.optimize import linear_sum_assignment
 
 from ..array_utils import box_pairs, merge_boxes, merge_rles, rle_pair_intersections
+from .deferred import _Pending
 from .rle import pan_seg_to_rle_seg, rle_seg_to_pan_seg, unpack_rle_attrs
 
 __all__ = ['rle_matcher', 'RLEMatcher', 'SequentialMatcher', 'merge_attrs']
@@ -88,6 +89,13 @@ class RLEMatcher:
         self.assign_new = assign_new
         self.next_label = (class_id * label_divisor) + 1
         self.target_rle = None
+
+    def __getstate__(self):
+        """pickling (matchers cross mp.Queues in the reference's scripts): a matcher whose slices are deferred
+        (inference/deferred.py) files them first, so that target AND label counter are the real ones"""
+        if isinstance(self.target_rle, _Pending):
+            self.target_rle.resolve()
+        return self.__dict__.copy()
 
     def initialize_target(self, target_instance_rles):
         self.target_rle = target_instance_rles

@@ -112,6 +112,9 @@ def _protocol(heads, axis, shape3d, labels, thing, ks, deferred, look=None, batc
         if look == 'seg' and n == 4:
             seen['seg'] = sorted(seg[thing[0]].keys())
             seen['next_label'] = matchers[0].next_label
+        if look == 'pickle_matcher' and n == 4:            # matchers cross mp.Queues in the reference's scripts
+            clone = pickle.loads(pickle.dumps(matchers[0]))
+            seen['clone'] = [clone.next_label] + sorted(clone.target_rle.keys())
         stack.append(seg)
 
     for t in range(S):
@@ -142,7 +145,7 @@ def test_deferred_protocol_fills_the_trackers_like_the_per_slice_protocol(axis, 
     labels = [1] if C == 1 else [1, 2, 3]
     exp_full, _, _ = _protocol(heads, axis, shape, labels, thing, 5, deferred=False)
     assert sum(len(t.instances) for t in exp_full) > 5
-    for look in (None, 'pan', 'rle', 'seg', 'final', 'instances', 'script', 'no_end'):
+    for look in (None, 'pan', 'rle', 'seg', 'final', 'instances', 'script', 'no_end', 'pickle_matcher'):
         got, seen, eng = _protocol(heads, axis, shape, labels, thing, 5, deferred=True, look=look)
         ref = _protocol(heads, axis, shape, labels, thing, 5, deferred=False, look=look) if look else (exp_full, {})
         exp, ref_seen = ref[0], ref[1]

@@ -54,6 +54,7 @@ def test_handles_chain_without_computing_and_unknown_uses_compute():
     assert tuple(pan.shape) == (1, 1, 4, 4)                                # attribute access computes
     assert int(torch.sum(pan)) == 120                                      # torch functions compute
     assert (pan + 1)[0, 0, 0, 0] == 1
+    assert torch.stack([pan, pan]).shape == (2, 1, 1, 4, 4)                # handles inside containers too
 
 
 def test_a_model_that_answers_one_image_per_call_is_refused_when_batched():
