@@ -145,7 +145,7 @@ def get_panoptic_segmentation(sem, ctr_hmp, offsets, thing_list: List[int], labe
 # ----------------------------------------------------------------------------- batched fast path
 def panoptic_stack(sem_prob, ctr_hmp, offsets, *, thing_list, label_divisor=1000, stuff_area=64, void_label=0,
                    nms_threshold=0.1, nms_kernel=7, confidence_thr=0.5, median_kernel_size=3, coarse_boundaries=True,
-                   upsampling=1, n_classes=None):
+                   upsampling=1, n_classes=None, out_dtype=torch.uint32):
     """Whole-stack form of the 3d engines (engines.py:161-221, 327-394): everything from probabilities
     to panoptic labels for D slices in five kernel groups, no host round trip per slice.
 
@@ -169,7 +169,9 @@ def panoptic_stack(sem_prob, ctr_hmp, offsets, *, thing_list, label_divisor=1000
         ks = 1
         D = len(emitted)
     if D == 0:
-        return torch.zeros((0, Hp, Wp), dtype=torch.int32, device=sem_prob.device).view(torch.uint32), emitted
+        empty = torch.zeros((0, Hp, Wp), dtype=torch.int32 if out_dtype == torch.uint32 else out_dtype,
+                            device=sem_prob.device)
+        return (empty.view(torch.uint32) if out_dtype == torch.uint32 else empty), emitted
     sem = _hip.median_harden_stack(sem_prob, ks, confidence_thr)
     step = 4 if coarse_boundaries else 1
     idx, cnt = centers_batched(ctr_hmp, nms_threshold, nms_kernel)
@@ -179,5 +181,5 @@ def panoptic_stack(sem_prob, ctr_hmp, offsets, *, thing_list, label_divisor=1000
     if n_classes is None:
         n_classes = max(2 if C == 1 else C, max(thing_list) + 1)
     pan = _hip.fuse_panoptic(sem, ids, idx.shape[1], n_classes, thing_list, label_divisor, stuff_area, void_label,
-                             up=int(step * upsampling))
+                             up=int(step * upsampling), out_dtype=out_dtype)
     return pan, emitted

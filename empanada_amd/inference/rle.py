@@ -62,14 +62,20 @@ def stack_to_rle_segs(pan, labels, label_divisor, thing_list, force_connected=Tr
     cc = [l for l in labels if (force_connected and l in thing_list)]
     table = _hip.extract_runs(pan, label_divisor, cc)
     D = table.D
-    r_start = table.r_start.cpu().numpy()
-    r_len = table.r_len.cpu().numpy()
-    r_comp = table.r_comp.cpu().numpy()
-    c_slice = table.c_slice.cpu().numpy()
-    c_label = table.c_label.cpu().numpy()
-    c_box = table.c_box.cpu().numpy()
+    # one device-to-host copy for the whole table (eight copies were eight synchronisations per call -- per SLICE in the
+    # per-slice protocol): every column as int64 in one buffer, cut up on the host
+    nr, nc = int(table.n_runs), int(table.n_comp)
+    cols = [table.r_start, table.r_len, table.r_comp, table.r_val.view(torch.int32), table.c_slice, table.c_label,
+            table.c_box.reshape(-1), table.c_first]
+    flat = torch.cat([c.reshape(-1).to(torch.int64) for c in cols]).cpu().numpy() if nr else np.zeros(0, np.int64)
+    cut = np.cumsum([0, nr, nr, nr, nr, nc, nc, 4 * nc, nc])
+    part = lambda i: flat[cut[i]:cut[i + 1]] if nr else np.zeros(0, np.int64)
+    r_start, r_len, r_comp = part(0).astype(np.int32), part(1).astype(np.int32), part(2).astype(np.int32)
+    r_val = (part(3) & 0xFFFFFFFF).astype(np.uint32)                 # the int32 view sign-extends labels >= 2^31
+    c_slice, c_label = part(4).astype(np.int32), part(5)
+    c_box, c_first = part(6).astype(np.int32).reshape(-1, 4), part(7)
     # the class of a component is that of its ORIGINAL value: relabelled ids may run past the divisor
-    c_val = table.r_val.cpu().numpy()[table.c_first.cpu().numpy()] if table.n_comp else np.zeros(0, np.uint32)
+    c_val = r_val[c_first] if nc else np.zeros(0, np.uint32)
     starts, runs, off = runs_to_instances(r_start, r_len, r_comp, table.n_comp)
     segs = [{l: {} for l in labels} for _ in range(D)]
     if table.n_comp:
