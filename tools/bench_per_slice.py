@@ -101,6 +101,8 @@ def main():
             t0 = time.perf_counter()
             proc.start()
             tick('mp.Process(...).start(): fork of the process that holds the GPU', t0)
+            if os.environ.get('EMP_SCRIPT_SLEEP'):         # experiment: a pause after the fork
+                time.sleep(float(os.environ['EMP_SCRIPT_SLEEP']))
             t0 = time.perf_counter()
             for t in range(D):
                 pan = eng(images[t])
