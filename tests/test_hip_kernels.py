@@ -366,6 +366,38 @@ def test_fill_overlapping_order(hip):
     got = AU.numpy_fill_instances(np.zeros((10, 20, 25), np.uint32), inst)
     np.testing.assert_array_equal(got, exp)
 
+def test_numpy_fill_instances_into_every_kind_of_volume():
+    """array_utils.py:725-737 through the GPU paint: a fresh volume (nothing uploaded, labels copied straight into the
+    caller's memory), a volume that already holds labels (later instances overwrite, the rest stays), other integer
+    widths and a non-contiguous view (staged copy); the caller's array is filled IN PLACE"""
+    from empanada_amd import array_utils as AU
+    from oracle import rle_ops as OR
+    rng = np.random.default_rng(3)
+    shape = (6, 17, 23)
+    n = int(np.prod(shape))
+    inst = {}
+    for i in range(9):
+        starts = np.sort(rng.choice(n - 40, size=12, replace=False)).astype(np.int64)
+        inst[1000 + 7 * i] = {'box': (0, 0, 0, 1, 1, 1), 'starts': starts, 'runs': rng.integers(1, 30, size=12).astype(np.int64)}
+    for dtype in (np.uint32, np.int32, np.uint16, np.uint8):
+        ids = {k % (250 if dtype == np.uint8 else 60000 if dtype == np.uint16 else 2 ** 31): v for k, v in inst.items()}
+        fresh = np.zeros(shape, dtype)
+        out = AU.numpy_fill_instances(fresh, ids)
+        exp = OR.numpy_fill_instances(np.zeros(shape, dtype), ids)
+        np.testing.assert_array_equal(out, exp)
+        np.testing.assert_array_equal(fresh, exp)                # in place
+        used = rng.integers(0, 200, size=shape).astype(dtype)    # already labelled: upload, paint over, copy back
+        exp2 = OR.numpy_fill_instances(used.copy(), ids)
+        AU.numpy_fill_instances(used, ids)
+        np.testing.assert_array_equal(used, exp2)
+    big = np.zeros((6, 17, 46), np.uint32)
+    view = big[:, :, ::2]                                        # not contiguous: reshape(-1) copies, the result is returned
+    out = AU.numpy_fill_instances(view, inst)
+    np.testing.assert_array_equal(out, OR.numpy_fill_instances(np.zeros(shape, np.uint32), inst))
+    with pytest.raises(ValueError):
+        AU.numpy_fill_instances(np.zeros(shape, np.int64), inst)
+
+
 
 def test_sort(hip):
     rng = np.random.default_rng(16)
