@@ -241,7 +241,8 @@ def merge_rles(starts_a, runs_a, starts_b=None, runs_b=None):
 
 
 def numpy_fill_instances(volume, instances):
-    """array_utils.py:725-737: paint the instances into `volume` (numpy, in place) on the GPU."""
+    """array_utils.py:725-737: paint the instances into `volume` (numpy, in place) on the GPU.  Instance ids are labels
+    (class * divisor + n >= 1); an id of 0 paints nothing (emp_fill_runs_u32 uses 0 for "skip this instance")."""
     _hip.require_gpu()
     ids = list(instances.keys())
     if not ids:

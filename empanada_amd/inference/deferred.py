@@ -292,14 +292,31 @@ class StackSession:
         if self._pan is None:
             assert self.closed and self.uniform
             self._flush(self.calls)
-            heads = {k: (torch.cat([c[2][k] for c in self.chunks], dim=0) if len(self.chunks) > 1
-                         else self.chunks[0][2][k]) for k in _HEADS}
+            heads = self._consolidate()
             pan, emitted = self.engine._deferred_stack(heads, self.upsampling)
             assert len(emitted) == self.n_emitted
             if self.size is not None:
                 pan = pan[:, :self.size[0], :self.size[1]].contiguous()
             self._pan = pan
         return self._pan
+
+    def _consolidate(self):
+        """the batches' head tensors as ONE tensor per head, copied batch by batch and freed as they go (a torch.cat
+        would hold the stack twice: 137 GB of heads for 1024 slices of 2048^2 with five classes); the session keeps
+        the result as its only chunk, so that values on demand still find their slice"""
+        if len(self.chunks) == 1 and self.chunks[0][0] == 0 and self.chunks[0][1] == self.n_fwd:
+            return self.chunks[0][2]
+        heads = {}
+        for k in _HEADS:
+            first = self.chunks[0][2][k]
+            out = torch.empty((self.n_fwd,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+            for lo, hi, part in self.chunks:
+                out[lo:hi].copy_(part[k])
+                part[k] = None
+            heads[k] = out
+        self.chunks = [(0, self.n_fwd, heads)]
+        self.chunk_of = [0] * self.n_fwd
+        return heads
 
     def tracker_instances(self, axis, shape3d, class_id):
         """the finished tracker of one class: what update_trackers over the backward pass + finish leave"""

@@ -380,7 +380,8 @@ def test_numpy_fill_instances_into_every_kind_of_volume():
         starts = np.sort(rng.choice(n - 40, size=12, replace=False)).astype(np.int64)
         inst[1000 + 7 * i] = {'box': (0, 0, 0, 1, 1, 1), 'starts': starts, 'runs': rng.integers(1, 30, size=12).astype(np.int64)}
     for dtype in (np.uint32, np.int32, np.uint16, np.uint8):
-        ids = {k % (250 if dtype == np.uint8 else 60000 if dtype == np.uint16 else 2 ** 31): v for k, v in inst.items()}
+        # labels are class * divisor + n >= 1: id 0 never occurs (and means "paint nothing" to emp_fill_runs_u32)
+        ids = {k % (249 if dtype == np.uint8 else 60000 if dtype == np.uint16 else 2 ** 31) + 1: v for k, v in inst.items()}
         fresh = np.zeros(shape, dtype)
         out = AU.numpy_fill_instances(fresh, ids)
         exp = OR.numpy_fill_instances(np.zeros(shape, dtype), ids)
