@@ -60,37 +60,6 @@ def _bn_affine(bn):
     return scale, shift
 
 
-_SIDE_STREAMS = {}
-
-
-def _run_branches(fns):
-    """Run independent closures (they write disjoint tensors) and return their results in order.
-
-    While a HIP graph is being captured (models/graphed.py) the closures after the first are forked onto side streams
-    and joined again, so that the captured graph holds them as PARALLEL branches: at batch 1 a branch is a chain of
-    launches of 8-256 workgroups each (ASPP's five branches, a bottleneck's shortcut projection beside its main path, the
-    three heads), and replayed side by side they share the 256 CUs instead of taking turns on a fraction of them.
-    Outside a capture -- eager calls, where the host is the bottleneck and stream switches would only add to it -- the
-    closures simply run one after the other; results are the same either way."""
-    if len(fns) < 2 or not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
-        return [f() for f in fns]
-    cur = torch.cuda.current_stream()
-    pool = _SIDE_STREAMS.setdefault(cur.device, [])
-    while len(pool) < len(fns) - 1:
-        pool.append(torch.cuda.Stream(device=cur.device))
-    side = pool[:len(fns) - 1]
-    for st in side:
-        st.wait_stream(cur)                              # fork
-    outs = [None] * len(fns)
-    for i, st in enumerate(side):
-        with torch.cuda.stream(st):
-            outs[i + 1] = fns[i + 1]()
-    outs[0] = fns[0]()
-    for st in side:
-        cur.wait_stream(st)                              # join
-    return outs
-
-
 def _no_late_weights(state_dict, prefix, *args):
     """The inference stand-ins fold their weights at construction (BatchNorm -> scale / shift, filters permuted or
     Winograd-transformed): loading a state dict into a prepared model would leave those stale.  Fail loudly."""
@@ -357,12 +326,9 @@ class _Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        if isinstance(self.conv1, FusedConvBNAct):
-            if self.downsample is None:
-                return self.conv3(self.conv2(self.conv1(x)), x)
-            mid, idt = _run_branches([lambda: self.conv2(self.conv1(x)), lambda: self.downsample(x)])
-            return self.conv3(mid, idt)
         idt = x if self.downsample is None else self.downsample(x)
+        if isinstance(self.conv1, FusedConvBNAct):
+            return self.conv3(self.conv2(self.conv1(x)), idt)
         if isinstance(self.bn1, FusedBNAct):
             out = self.bn2(self.conv2(self.bn1(self.conv1(x))))
             return self.bn3(self.conv3(out), idt)
@@ -499,12 +465,12 @@ class ASPP(nn.Module):
             n = self.nout
             buf = torch.empty((x.shape[0], len(self.convs) * n, x.shape[2], x.shape[3]), dtype=x.dtype,
                               device=x.device, memory_format=torch.channels_last)
-            def branch(i, conv):
+            for i, conv in enumerate(self.convs):
                 dst = buf[:, i * n:(i + 1) * n]
                 if isinstance(conv, _ASPPPooling):
-                    return lambda: conv(x, out=dst)
-                return lambda: _conv_bn_into(conv, x, dst)
-            _run_branches([branch(i, conv) for i, conv in enumerate(self.convs)])
+                    conv(x, out=dst)
+                else:
+                    _conv_bn_into(conv, x, dst)
             return self.project(buf)
         return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
 
@@ -611,10 +577,9 @@ class PanopticDeepLab(nn.Module):
         pyramid = self.encoder(x)
         sem_x = self.semantic_decoder(pyramid)
         ins_x = sem_x if self.instance_decoder is None else self.instance_decoder(pyramid)
-        sem, ctr, off = _run_branches([lambda: self._up4(self.semantic_head(sem_x)),
-                                       lambda: self._up4(self.ins_center(ins_x)),
-                                       lambda: self._up4(self.ins_xy(ins_x))])
-        return {'sem_logits': sem, 'ctr_hmp': ctr, 'offsets': off}
+        return {'sem_logits': self._up4(self.semantic_head(sem_x)),
+                'ctr_hmp': self._up4(self.ins_center(ins_x)),
+                'offsets': self._up4(self.ins_xy(ins_x))}
 
 
 # ----------------------------------------------------------------------------- PointRend (inference)
@@ -741,24 +706,16 @@ class PanopticDeepLabPR(PanopticDeepLab):
 
     def forward(self, x, render_steps: int = 2, interpolate_ins: bool = True):
         pyramid = self.encoder(x)
+        sem_x = self.semantic_decoder(pyramid)
+        ins_x = sem_x if self.instance_decoder is None else self.instance_decoder(pyramid)
         self.semantic_pr.subdivision_steps = render_steps
-
-        def semantic():
-            # PointRend: on the GPU the features stay NHWC (emp_pr_point_sample gathers whole pixels); the library path
-            # makes them NCHW-contiguous itself
-            sem_x = self.semantic_decoder(pyramid)
-            return sem_x, self.semantic_pr(self.semantic_head(sem_x).float().contiguous(), sem_x.float())
-
-        def instance(ins_x):
-            ctr, off = self.ins_center(ins_x), self.ins_xy(ins_x)
-            return (self._up4(ctr) if interpolate_ins else ctr), (self._up4(off) if interpolate_ins else off)
-
-        if self.instance_decoder is None:
-            sem_x, sem = semantic()
-            ctr, off = instance(sem_x)
-        else:                        # two decoders on the same pyramid: independent until the outputs
-            (sem_x, sem), (ctr, off) = _run_branches([semantic, lambda: instance(self.instance_decoder(pyramid))])
-        return {'sem_logits': sem['sem_seg_logits'], 'ctr_hmp': ctr, 'offsets': off}
+        # PointRend: on the GPU the features stay NHWC (emp_pr_point_sample gathers whole pixels); the library path
+        # makes them NCHW-contiguous itself
+        sem = self.semantic_pr(self.semantic_head(sem_x).float().contiguous(), sem_x.float())
+        ctr, off = self.ins_center(ins_x), self.ins_xy(ins_x)
+        return {'sem_logits': sem['sem_seg_logits'],
+                'ctr_hmp': self._up4(ctr) if interpolate_ins else ctr,
+                'offsets': self._up4(off) if interpolate_ins else off}
 
 
 # ----------------------------------------------------------------------------- deployment helpers
