@@ -425,6 +425,12 @@ def vote_ranges(starts, ends, grp, n_groups, vote_thr):
 
 def rle_pair_intersections(starts, lens, inst_off, pairs):
     require_gpu()
+    n = _expect("rle_pair_intersections: starts", starts, torch.int64).numel()
+    _expect("rle_pair_intersections: lengths", lens, torch.int64, numel=n)
+    _expect("rle_pair_intersections: instance offsets", inst_off, torch.int64)
+    _expect("rle_pair_intersections: pairs", pairs, torch.int32)
+    if pairs.dim() != 2 or pairs.shape[1] != 2:
+        raise HipError(f"rle_pair_intersections: pairs must be (n, 2), got {tuple(pairs.shape)}")
     n_pairs = pairs.shape[0]
     out = torch.empty((n_pairs,), dtype=torch.int64, device=starts.device)
     call('emp_rle_pair_intersections', _ptr(starts), _ptr(lens), _ptr(inst_off), _ptr(pairs.contiguous()), n_pairs,
@@ -461,7 +467,14 @@ def box_pairs(boxes_a, boxes_b=None, src_a=None, src_b=None, upper_only=False):
     self_pairs = boxes_b is None
     if self_pairs:
         boxes_b, src_b = boxes_a, src_a
+    _expect("box_pairs: boxes", boxes_a, torch.int32)
+    _expect("box_pairs: boxes", boxes_b, torch.int32)
+    if boxes_a.dim() != 2 or boxes_b.dim() != 2 or boxes_a.shape[1] != boxes_b.shape[1] or boxes_a.shape[1] not in (4, 6):
+        raise HipError(f"box_pairs: boxes must be (n, 4) or (n, 6), got {tuple(boxes_a.shape)} and {tuple(boxes_b.shape)}")
     na, nb = boxes_a.shape[0], boxes_b.shape[0]
+    for what, src, n_ in (("src_a", src_a, na), ("src_b", src_b, nb)):
+        if src is not None:
+            _expect(f"box_pairs: {what}", src, torch.int32, numel=n_)
     nd = boxes_a.shape[1] // 2
     dev = boxes_a.device
     cap = max(16 * (na + nb), 4096)
@@ -490,8 +503,11 @@ def bn_act_nhwc_(x, scale, shift, residual=None, relu=True, out=None):
     written to `out`: an (N,C,H,W) channel slice of a wider channels_last buffer."""
     N, C, H, W = x.shape
     assert x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32
+    _expect("bn_act: scale", scale, torch.float32, (C,))
+    _expect("bn_act: shift", shift, torch.float32, (C,))
     if residual is not None:
         assert residual.shape == x.shape and residual.is_contiguous(memory_format=torch.channels_last)
+        _expect("bn_act: residual", residual, torch.float32)
     ostride = 0
     dst = x
     if out is not None:
@@ -538,7 +554,8 @@ def yz_runs_along_x(table, value_u32, shape3d, slice0=0):
 def rle_decode(starts, runs):
     """device int64 (starts, runs) -> int64 indices (emp_rle_decode); offsets via torch.cumsum (plumbing)."""
     require_gpu()
-    n = starts.numel()
+    n = _expect("rle_decode: starts", starts, torch.int64).numel()
+    _expect("rle_decode: runs", runs, torch.int64, numel=n)
     if n == 0:
         return torch.zeros(0, dtype=torch.int64, device=starts.device)
     csum = torch.cumsum(runs, 0)
@@ -551,7 +568,7 @@ def rle_decode(starts, runs):
 def rle_encode(indices):
     """device int64 ascending indices -> (starts, runs) int64 (emp_rle_encode)."""
     require_gpu()
-    n = indices.numel()
+    n = _expect("rle_encode: indices", indices, torch.int64).numel()
     dev = indices.device
     work = torch.empty((query('emp_rle_encode_work_elems', n),), dtype=torch.int32, device=dev)
     st = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
@@ -604,6 +621,14 @@ def conv_bn_act_nhwc(x, w_okkc, scale=None, shift=None, residual=None, relu=Fals
     N, Cin, H, W = x.shape
     Cout, KH, KW, _ = w_okkc.shape
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    _expect("conv: weights", w_okkc, torch.float32)
+    if w_okkc.shape[3] != Cin or not w_okkc.is_contiguous():
+        raise HipError(f"conv: weights must be a contiguous (Cout, KH, KW, Cin = {Cin}) tensor, got {tuple(w_okkc.shape)}")
+    for what, t in (("scale", scale), ("shift", shift)):
+        if t is not None:
+            _expect(f"conv: {what}", t, torch.float32, (Cout,))
+    if residual is not None:
+        _expect("conv: residual", residual, torch.float32)
     OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
     OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
 
@@ -639,6 +664,14 @@ def conv_splitk_bn_act_nhwc(x, w_okkc, scale=None, shift=None, residual=None, re
     N, Cin, H, W = x.shape
     Cout, KH, KW, _ = w_okkc.shape
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    _expect("conv: weights", w_okkc, torch.float32)
+    if w_okkc.shape[3] != Cin or not w_okkc.is_contiguous():
+        raise HipError(f"conv: weights must be a contiguous (Cout, KH, KW, Cin = {Cin}) tensor, got {tuple(w_okkc.shape)}")
+    for what, t in (("scale", scale), ("shift", shift)):
+        if t is not None:
+            _expect(f"conv: {what}", t, torch.float32, (Cout,))
+    if residual is not None:
+        _expect("conv: residual", residual, torch.float32)
     OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
     OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
     M = N * OH * OW
