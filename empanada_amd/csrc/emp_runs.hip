@@ -121,29 +121,49 @@ __global__ __launch_bounds__(256) void row_runs_kernel(const uint32_t *__restric
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;            // lanes before this one
+    auto fetch = [&](const uint32_t *src, int x0, uint32_t (&v)[VEC]) {
+        const int x = x0 + lane * VEC;
+        if (VEC == 4) {
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (x < W) q = *reinterpret_cast<const uint4 *>(src + x);   // W % 4 == 0 on this path
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            v[0] = (x < W) ? src[x] : 0u;
+        }
+    };
     for (int64_t row = wave; row < n_rows; row += n_waves) {
         const uint32_t *src = pan + row * W;
         const int y = (int)(row % H);
         int n_s = 0, n_e = 0;  // wave-uniform running counts of starts / ends in this row
         int32_t obase = EXTRACT ? row_offsets[row] : 0;
+        // the chunk after the current one is requested before the current one is scanned (two loads in flight per
+        // lane), and the two values a wave cannot get from a neighbouring lane come from the chunks in registers:
+        // left of lane 0 = the previous chunk's last pixel, right of lane 63 = the next chunk's first (no dependent
+        // loads inside the loop)
+        uint32_t cur[VEC], nxt[VEC];
+        fetch(src, 0, cur);
+        uint32_t carry = 0u;                                            // pixel left of the chunk (0 at the row start)
         for (int x0 = 0; x0 < W; x0 += 64 * VEC) {
-            int x = x0 + lane * VEC;
-            uint32_t v[VEC + 2];  // v[0] = left neighbour, v[VEC+1] = right neighbour
-            if (VEC == 4) {
-                uint4 q = make_uint4(0, 0, 0, 0);
-                if (x < W) q = *reinterpret_cast<const uint4 *>(src + x);
-                v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w;
-            } else {
-                v[1] = (x < W) ? src[x] : 0u;
+            const int x = x0 + lane * VEC;
+            const bool more = x0 + 64 * VEC < W;
+            if (more) fetch(src, x0 + 64 * VEC, nxt);
+            else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) nxt[j] = 0u;
             }
+            uint32_t v[VEC + 2];  // v[0] = left neighbour, v[VEC+1] = right neighbour
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j + 1] = cur[j];
             uint32_t left = __shfl_up(v[VEC], 1);
             uint32_t right = __shfl_down(v[1], 1);
-            if (lane == 0) left = (x > 0) ? src[x - 1] : 0u;
-            if (lane == 63) right = (x + VEC < W) ? src[x + VEC] : 0u;
+            const uint32_t next_first = __shfl(nxt[0], 0);
+            if (lane == 0) left = carry;
+            if (lane == 63) right = next_first;                         // 0 past the row's end
             v[0] = left;
             v[VEC + 1] = right;
-            int ls = 0, le = 0;
             bool st[VEC], en[VEC];
+            unsigned long long bs[VEC], be[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 bool in = (x + j) < W;
@@ -151,19 +171,23 @@ __global__ __launch_bounds__(256) void row_runs_kernel(const uint32_t *__restric
                 uint32_t nb_r = ((x + j + 1) < W) ? v[j + 2] : 0u;
                 st[j] = in && c != 0 && c != v[j];
                 en[j] = in && c != 0 && c != nb_r;
-                ls += st[j];
-                le += en[j];
+                bs[j] = __ballot(st[j]);
+                be[j] = __ballot(en[j]);
             }
-            // wave-exclusive prefix of the per-lane counts
-            int ps = ls, pe = le;
+            // positions by ballot + population count: starts (ends) of the lanes before this one, all sub-positions;
+            // the lane's own follow in sub-position order -- raster order, since pixel = lane * VEC + j
+            int tot_s = 0, tot_e = 0, ps = 0, pe = 0;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                int a = __shfl_up(ps, off), b = __shfl_up(pe, off);
-                if (lane >= off) { ps += a; pe += b; }
+            for (int j = 0; j < VEC; ++j) {
+                tot_s += __popcll(bs[j]);
+                tot_e += __popcll(be[j]);
+                if (EXTRACT) {
+                    ps += __popcll(bs[j] & below);
+                    pe += __popcll(be[j] & below);
+                }
             }
-            int tot_s = __shfl(ps, 63), tot_e = __shfl(pe, 63);
             if (EXTRACT) {
-                int is = obase + n_s + ps - ls, ie = obase + n_e + pe - le;
+                int is = obase + n_s + ps, ie = obase + n_e + pe;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     if (st[j]) { r_start[is] = y * W + x + j; r_val[is] = v[j + 1]; ++is; }
@@ -172,6 +196,9 @@ __global__ __launch_bounds__(256) void row_runs_kernel(const uint32_t *__restric
             }
             n_s += tot_s;
             n_e += tot_e;
+            carry = __shfl(cur[VEC - 1], 63);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) cur[j] = nxt[j];
         }
         if (!EXTRACT && lane == 0) row_counts[row] = n_s;
     }
