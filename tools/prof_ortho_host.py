@@ -1,31 +1,27 @@
-"""cProfile of the host side of one orthoplane pass (512^3): where the tail (tracking, consensus) goes.
-usage: PYTHONPATH=. python tools/prof_ortho_host.py"""
+"""cProfile of the host side of the post-processing of one orthoplane pass (planted heads, no forward): where the
+replicated host terms of the N-rank path go (chain, instance tables, consensus tables).
+usage: python tools/prof_ortho_host.py [size]"""
 import cProfile
+import os
 import pstats
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-sys.argv = ['bench.py', '--mode', 'orthoplane', '--size', '512', '--no-tune']
 import bench
 
-args = bench.parse()
-device = torch.device('cuda', 0)
-from empanada_amd import _hip
-_hip.load()
-torch.backends.cudnn.benchmark = True
-S = args.size
-stacks, heads, n_obj, slice0 = bench.build_inputs_ortho(S, device)
-pipe = bench.Pipeline(args, device)
-host_out = torch.empty((S, S, S), dtype=torch.int32).pin_memory()
-bench.orthoplane_step(pipe, stacks, heads, slice0, (S, S, S), host_out, {})
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+dev = torch.device('cuda', 0)
+stacks, heads, n_obj, _ = bench.build_inputs_ortho(S, dev)
+del stacks
+bench.postprocess_planes(heads, (S, S, S), None, {})
 torch.cuda.synchronize()
 pr = cProfile.Profile()
-pr.enable()
 stages = {}
-bench.orthoplane_step(pipe, stacks, heads, slice0, (S, S, S), host_out, stages)
+pr.enable()
+bench.postprocess_planes(heads, (S, S, S), None, stages)
 torch.cuda.synchronize()
 pr.disable()
-print(stages)
-st = pstats.Stats(pr)
-st.sort_stats('cumulative').print_stats(45)
+print({k: round(v, 4) for k, v in stages.items()})
+pstats.Stats(pr).sort_stats('tottime').print_stats(28)
