@@ -22,6 +22,9 @@ anything that looks inside a handle) needs a value:
 So the values are those of the per-slice protocol whichever way they are obtained (up to the float boundary of
 DESIGN.md: the forward runs in batches of ``deferred_batch`` images rather than one).
 """
+import functools
+import threading
+
 import numpy as np
 import torch
 
@@ -61,10 +64,20 @@ def _same(x):
     return x
 
 
+def _locked(method):
+    """session state is touched from wherever a handle is looked at -- an mp.Queue pickles in its feeder THREAD"""
+    @functools.wraps(method)
+    def guarded(self, *args, **kwargs):
+        with self._lock:
+            return method(self, *args, **kwargs)
+    return guarded
+
+
 class StackSession:
     """One stack of slices handed to a 3d engine one image at a time."""
 
     def __init__(self, engine, batch_size=16):
+        self._lock = threading.RLock()
         self.engine = engine
         self.batch = max(int(batch_size), 1)
         self.ks, self.m = engine.ks, engine.mid_idx
@@ -97,6 +110,7 @@ class StackSession:
         self._tracks = {}
 
     # ------------------------------------------------------------------ engine side
+    @_locked
     def add(self, image, size=None, upsampling=1):
         assert not self.closed
         if self.calls == 0:
@@ -121,6 +135,7 @@ class StackSession:
         k, self.n_emitted = self.n_emitted, self.n_emitted + 1
         return LazyPan(self, k)
 
+    @_locked
     def end(self):
         """_MedianQueue.end: the items right of the middle (none while the queue holds at most ks // 2 + 1)"""
         assert not self.closed
@@ -153,6 +168,7 @@ class StackSession:
         return out
 
     # ------------------------------------------------------------------ values on demand (replay of the per-slice code)
+    @_locked
     def force_pan(self, k):
         eng = self.engine
         while len(self.eager_out) <= k:
@@ -170,6 +186,7 @@ class StackSession:
                 raise RuntimeError("deferred engine: slice requested before the engine has seen enough images")
         return self.eager_out[k]
 
+    @_locked
     def go_eager(self):
         """bring the engine's own median queue to where the reference's would be after the calls so far"""
         if self.n_emitted:
@@ -188,6 +205,7 @@ class StackSession:
             seg._real = rle.pan_seg_to_rle_seg(pan, *self.rle_args)
         return seg._real
 
+    @_locked
     def _forward_now(self):
         """replay apply_matchers over every slice that went through it, in order, on the matchers themselves"""
         from . import patterns
@@ -201,12 +219,14 @@ class StackSession:
             patterns._apply_matchers_now(self._rle_now(self.eager_matched), self.matchers)
             self.eager_matched += 1
 
+    @_locked
     def force_seg(self, k):
         real = self._rle_now(k)
         if self.segs[k]._matched:
             self._forward_now()
         return real
 
+    @_locked
     def _backward_now(self):
         from . import patterns
         if self.bwd == 'lazy':
@@ -216,6 +236,7 @@ class StackSession:
             for idx, rs in patterns._backward_matching_now(stack, self.matchers, self.n_emitted):
                 self.bwd_real[idx] = rs
 
+    @_locked
     def force_final(self, k):
         self._backward_now()
         return self.bwd_real[k]
@@ -224,6 +245,7 @@ class StackSession:
     def _stack_ok(self):
         return self.uniform and self.fwd_lazy
 
+    @_locked
     def lazy_rle(self, pan, args):
         """pan_seg_to_rle_seg on a handle -> LazySeg, or None when the call has to be computed now"""
         labels, div, things, force_connected = args
@@ -237,6 +259,7 @@ class StackSession:
         seg = self.segs[pan._k] = LazySeg(self, pan._k)
         return seg
 
+    @_locked
     def lazy_apply(self, seg, matchers):
         """apply_matchers on a handle: True when recorded, False when it has to run now"""
         from .matcher import RLEMatcher
@@ -266,6 +289,7 @@ class StackSession:
             self._forward_now()
         return False
 
+    @_locked
     def note_applied_now(self, seg):
         """apply_matchers ran on the spot for a slice of this stack (after _forward_now brought the matchers up to date)"""
         if self.bwd is None and not self.fwd_lazy and not seg._matched:
@@ -273,6 +297,7 @@ class StackSession:
             self.n_matched += 1
             self.eager_matched += 1
 
+    @_locked
     def lazy_backward(self, stack, matchers, axis_len):
         matchers = list(matchers)
         n = self.n_emitted
@@ -288,6 +313,7 @@ class StackSession:
 
     # ------------------------------------------------------------------ whole-stack evaluation
     @torch.no_grad()
+    @_locked
     def pan_stack(self):
         if self._pan is None:
             assert self.closed and self.uniform
@@ -318,6 +344,7 @@ class StackSession:
         self.chunk_of = [0] * self.n_fwd
         return heads
 
+    @_locked
     def tracker_instances(self, axis, shape3d, class_id):
         """the finished tracker of one class: what update_trackers over the backward pass + finish leave"""
         from . import device_tracks as DT

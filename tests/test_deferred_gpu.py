@@ -96,12 +96,19 @@ def _protocol(heads, axis, shape3d, labels, thing, ks, deferred, look=None, batc
     trackers = PA.create_axis_trackers({axis: 0}, labels, 1000, shape3d)[axis]
     stack, seen = [], {}
 
+    import multiprocessing
+    q = multiprocessing.Queue() if look == 'queue' else None
+
     def consume(pan):
         n = len(stack)
-        if look == 'script':                               # the reference script: a numpy array goes into an mp.Queue
+        if look == 'queue':                                # an mp.Queue pickles in its feeder THREAD, beside the engine calls
+            q.put(pan.squeeze().cpu().numpy())
+            pan = q.get(timeout=60)
+            assert isinstance(pan, np.ndarray)
+        elif look == 'script':                               # the reference script: a numpy array goes into an mp.Queue
             pan = pickle.loads(pickle.dumps(pan.squeeze().cpu().numpy()))
             assert isinstance(pan, np.ndarray)
-        else:
+        elif look != 'queue':
             pan = pan.squeeze().cpu().numpy()
         if look == 'pan' and n == 3:
             seen['pan'] = np.asarray(pan).copy()
@@ -145,7 +152,7 @@ def test_deferred_protocol_fills_the_trackers_like_the_per_slice_protocol(axis, 
     labels = [1] if C == 1 else [1, 2, 3]
     exp_full, _, _ = _protocol(heads, axis, shape, labels, thing, 5, deferred=False)
     assert sum(len(t.instances) for t in exp_full) > 5
-    for look in (None, 'pan', 'rle', 'seg', 'final', 'instances', 'script', 'no_end', 'pickle_matcher'):
+    for look in (None, 'pan', 'rle', 'seg', 'final', 'instances', 'script', 'no_end', 'pickle_matcher', 'queue'):
         got, seen, eng = _protocol(heads, axis, shape, labels, thing, 5, deferred=True, look=look)
         ref = _protocol(heads, axis, shape, labels, thing, 5, deferred=False, look=look) if look else (exp_full, {})
         exp, ref_seen = ref[0], ref[1]
