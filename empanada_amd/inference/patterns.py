@@ -89,18 +89,21 @@ def _gpu_process_entry(fn):
     items of the caller's queue go on to the worker's queue (a fork-context queue cannot be handed to a spawned process:
     its semaphores are unnamed), the worker's answer goes back through the caller's pipe.  The script runs unchanged; a
     few seconds of start-up per plane and one more pickle per image.  Anywhere else (main process, thread, spawned
-    process) the function runs in place.  Arguments 1 and 3 are the queue and the pipe end (both entry points)."""
+    process) the function runs in place."""
+    import inspect
+    signature = inspect.signature(fn)
+
     @functools.wraps(fn)
     def entry(*args, **kwargs):
         if not torch.cuda._is_in_bad_fork():
             return fn(*args, **kwargs)
         ctx = multiprocessing.get_context('spawn')
-        queue, matcher_in = args[1], args[3]
+        bound = signature.bind(*args, **kwargs)              # queue and pipe end by NAME, however they were passed
+        queue, matcher_in = bound.arguments['queue'], bound.arguments['matcher_in']
         work_queue = ctx.Queue()
         answer_out, answer_in = ctx.Pipe()
-        worker_args = list(args)
-        worker_args[1], worker_args[3] = work_queue, answer_in
-        proc = ctx.Process(target=entry, args=tuple(worker_args), kwargs=kwargs)
+        bound.arguments['queue'], bound.arguments['matcher_in'] = work_queue, answer_in
+        proc = ctx.Process(target=entry, args=bound.args, kwargs=bound.kwargs)
         proc.start()
         answer_in.close()
         while True:
