@@ -11,6 +11,9 @@ import json
 import math
 import os
 import shutil
+import bz2
+import gzip
+import lzma
 import zlib
 from concurrent.futures import ThreadPoolExecutor
 
@@ -149,8 +152,18 @@ class ZarrData:
 # `.zarray` JSON document per node and one file per chunk named by its dot-separated chunk index, C order,
 # little-endian, edge chunks padded to the full chunk shape with fill_value).  Compressor: none (raw bytes -- the
 # labelled slab goes from pinned memory to the file at memcpy speed) or stdlib zlib ({"id": "zlib"}, a numcodecs
-# codec every zarr reader has).  zarr's own default, Blosc, needs the blosc library and is not produced here; files
-# written by zarr with Blosc cannot be read here either (KeyError naming the codec).
+# codec every zarr reader has); stores compressed with the other numcodecs codecs the standard library covers (gzip,
+# bz2, lzma without filters) can be read and written too.  zarr's own default, Blosc, needs the blosc library and is not
+# produced here; files written by zarr with Blosc cannot be read here either (KeyError naming the codec).
+_CODECS = {
+    'zlib': (lambda raw: zlib.decompress(raw), lambda buf, lvl: zlib.compress(buf, lvl)),
+    'gzip': (lambda raw: gzip.decompress(raw), lambda buf, lvl: gzip.compress(bytes(buf), compresslevel=lvl)),
+    'bz2': (lambda raw: bz2.decompress(raw), lambda buf, lvl: bz2.compress(bytes(buf), max(lvl, 1))),
+    'lzma': (lambda raw: lzma.decompress(raw), lambda buf, lvl: lzma.compress(bytes(buf), preset=lvl)),
+}
+
+
+
 class ZarrV2Array:
     """One array of a zarr v2 directory store: shape / chunks / dtype attributes, slice get / set (whole chunks are
     read, modified and written back: what zarr_fill_instances needs), and `write_chunks` for bulk writes."""
@@ -163,8 +176,9 @@ class ZarrV2Array:
         if meta.get('zarr_format') != 2:
             raise ValueError(f"{path}: zarr_format {meta.get('zarr_format')} is not 2")
         comp = meta.get('compressor')
-        if comp is not None and comp.get('id') != 'zlib':
-            raise KeyError(f"{path}: compressor {comp.get('id')!r} is not available here (none or zlib only)")
+        if comp is not None and (comp.get('id') not in _CODECS or comp.get('filters') or comp.get('format', 1) != 1):
+            raise KeyError(f"{path}: compressor {comp.get('id')!r} is not available here "
+                           f"(none or {', '.join(sorted(_CODECS))}; Blosc needs the blosc library)")
         if meta.get('filters'):
             raise KeyError(f"{path}: filters are not supported")
         if meta.get('order', 'C') != 'C':
@@ -175,7 +189,8 @@ class ZarrV2Array:
         self.dtype = np.dtype(meta['dtype'])
         self.fill_value = meta.get('fill_value') or 0
         self.sep = meta.get('dimension_separator', '.')
-        self.zlib_level = None if comp is None else int(comp.get('level', 1))
+        self.codec = None if comp is None else comp['id']
+        self.zlib_level = None if comp is None else int(comp.get('level', comp.get('preset') or 1))
         self.nchunks = math.prod(math.ceil(s / c) for s, c in zip(self.shape, self.chunks))
         self.ndim = len(self.shape)
 
@@ -189,8 +204,8 @@ class ZarrV2Array:
             return np.full(self.chunks, self.fill_value, dtype=self.dtype)
         with open(p, 'rb') as fh:
             raw = fh.read()
-        if self.zlib_level is not None:
-            raw = zlib.decompress(raw)
+        if self.codec is not None:
+            raw = _CODECS[self.codec][0](raw)
         return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks).copy()
 
     def write_chunk(self, idx, data):
@@ -200,7 +215,7 @@ class ZarrV2Array:
             raise ValueError("write_chunk needs a full chunk")
         p = self._chunk_path(idx)
         with open(p, 'wb') as fh:
-            fh.write(zlib.compress(buf, self.zlib_level) if self.zlib_level is not None else buf)
+            fh.write(_CODECS[self.codec][1](buf, self.zlib_level) if self.codec is not None else buf)
 
     # -- slicing (basic slices with step 1, ints)
     def _norm(self, key):
@@ -298,7 +313,11 @@ class ZarrV2Group:
         shape = tuple(int(s) for s in shape)
         chunks = shape if chunks is None else tuple(int(s if c is None else c) for s, c in zip(shape, chunks))
         dt = np.dtype(dtype)
-        meta = {'chunks': list(chunks), 'compressor': None if compressor is None else {'id': 'zlib', 'level': int(compressor)},
+        if isinstance(compressor, dict):             # a numcodecs configuration, e.g. {'id': 'gzip', 'level': 1}
+            comp = dict(compressor)
+        else:
+            comp = None if compressor is None else {'id': 'zlib', 'level': int(compressor)}
+        meta = {'chunks': list(chunks), 'compressor': comp,
                 'dtype': dt.str if dt.itemsize > 1 else '|' + dt.str[1:], 'fill_value': fill_value, 'filters': None,
                 'order': 'C', 'shape': list(shape), 'zarr_format': 2}
         with open(os.path.join(path, '.zarray'), 'w') as fh:

@@ -73,6 +73,28 @@ def test_unsupported_codecs_fail_loudly(tmp_path):
         ZarrV2Array(str(p))
 
 
+@pytest.mark.parametrize('codec', [{'id': 'zlib', 'level': 1}, {'id': 'gzip', 'level': 1}, {'id': 'bz2', 'level': 1},
+                                   {'id': 'lzma', 'format': 1, 'check': -1, 'preset': 1, 'filters': None}])
+def test_stdlib_codecs_round_trip_and_decode_with_the_library(tmp_path, codec):
+    """chunk files of a compressed store are what the numcodecs codec of that id writes: the stdlib's own stream for
+    zlib / gzip / bz2 / lzma (decoded here with the library call directly, not through ZarrV2Array)"""
+    import bz2
+    import gzip
+    import lzma
+    import zlib
+    g = ZarrV2Group(str(tmp_path / 'c.zarr'))
+    a = g.create_dataset('v', shape=(5, 7, 9), dtype=np.uint16, chunks=(2, 7, 5), compressor=codec)
+    ref = np.arange(5 * 7 * 9, dtype=np.uint16).reshape(5, 7, 9)
+    a[...] = ref
+    b = open_zarr(str(tmp_path / 'c.zarr' / 'v'))
+    np.testing.assert_array_equal(b[...], ref)
+    raw = open(str(tmp_path / 'c.zarr' / 'v' / '1.0.1'), 'rb').read()
+    dec = {'zlib': zlib.decompress, 'gzip': gzip.decompress, 'bz2': bz2.decompress, 'lzma': lzma.decompress}[codec['id']](raw)
+    chunk = np.frombuffer(dec, dtype='<u2').reshape(2, 7, 5)
+    np.testing.assert_array_equal(chunk[:, :, :4], ref[2:4, :, 5:9])
+    assert json.load(open(str(tmp_path / 'c.zarr' / 'v' / '.zarray')))['compressor']['id'] == codec['id']
+
+
 def test_slab_writer_double_buffers(tmp_path):
     torch = pytest.importorskip('torch')
     g = ZarrV2Group(str(tmp_path / 'w.zarr'))
