@@ -66,12 +66,12 @@ ALG_BYTES = {
 # residual-prefetch and 64-wide variants, the weight-stationary 1x1 kernel at 1.00-1.07 -- against 7.672e12 algorithmic).
 PMC_TRAFFIC_RATIO = {
     'emp_conv_bn_act_nhwc': 1.18, 'emp_bn_act_nhwc': 1.0, 'emp_dwconv_nhwc': 1.06, 'emp_upsample_bilinear': 1.2,
-    'emp_median_harden_stack': 1.0, 'emp_find_centers': 1.14, 'emp_group_pixels': 1.26, 'emp_fuse_apply': 1.0,
-    'emp_runs_count': 1.0, 'emp_runs_extract': 1.04,
+    'emp_median_harden_stack': 1.02, 'emp_find_centers': 1.42, 'emp_group_pixels': 1.54, 'emp_fuse_apply': 1.0,
+    'emp_runs_count': 1.0, 'emp_runs_extract': 1.03,
 }
 PMC_SOURCE = ('offline PMC ratio x algorithmic bytes (profiles/r3_pmc_bench_ortho1024.md: rocprofv3 --pmc FETCH_SIZE / '
               'WRITE_SIZE passes over this workload at --size 1024; the other dense kernels r2_pmc_bench_ortho512.md, '
-              'the per-voxel kernels r1_pmc_postproc_256x512x512.md)')
+              'the per-voxel kernels r3_pmc_postproc_1024.md)')
 DENSE_KERNELS = ('emp_bn_act_nhwc', 'emp_dwconv_nhwc', 'emp_upsample_bilinear', 'emp_conv_bn_act_nhwc',
                  'emp_conv_splitk_bn_act_nhwc',
                  'emp_conv_bn_act_proj_nhwc', 'emp_wino_input_transform', 'emp_gemm_nt_batched', 'emp_wino_gemm_fused',
